@@ -1,0 +1,302 @@
+// bf16 MFMA GEMM for gfx950, "NT" form:  C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T)
+//
+// Every contraction on the STonKGs hot path is expressed in this one form (both operands
+// contraction-contiguous), which is the natural layout for nn.Linear (weight = [out, in]):
+//   forward   y  = x . W^T             A = x [T,in]        B = W [out,in]
+//   dgrad     dx = dy . W              A = dy [T,out]      B = W^T [in,out] (bf16 copy kept by the optimizer)
+//   wgrad     dW += dy^T . x           A = dy^T [out,T]    B = x^T [in,T]   (fp32 atomic accumulate, split-K)
+// Replaces torch addmm/mm issued by hf:models/bert/modeling_bert.py (BertSelfAttention :154-156,
+// BertSelfOutput :289-293, BertIntermediate :334-337, BertOutput :347-351, transform :476-480) and the
+// decoders of ref:src/stonkgs/models/stonkgs_model.py:47-49,70-71.
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16.
+// Operand tiles are staged global->LDS with 16-byte LDS-DMA (global_load_lds_dwordx4), double buffered;
+// the LDS image is lane-linear, the XOR swizzle (chunk ^ (row & 7)) is applied on the per-lane SOURCE
+// address and again on the ds_read_b128 fragment reads (conflict-free for 128-byte rows).
+#include "common.h"
+#include "stonk_flags.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
+constexpr int GEMM_LDS = 2 * STAGE_BYTES;      // double buffered: 64 KiB
+
+struct GemmArgs {
+  const bf16* A;
+  const bf16* B;
+  void* C;
+  const float* bias;
+  const bf16* resid;
+  bf16* aux;
+  const int* m_dev;
+  long lda, ldb, ldc, ldr, ldaux;
+  int M, N, K;
+  int flags;
+  float alpha;
+  int split_k;
+  uint32_t drop_thr24;
+  float drop_scale;
+  uint32_t seed;
+};
+
+// blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of tiles so
+// neighbouring tiles (same A row panel / same B column panel) hit the same L2. Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (b >> 3);
+}
+
+template <int OUT_MODE, bool GLDS>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int M = p.M;
+  if (p.m_dev) {
+    const int md = *p.m_dev;
+    M = md < M ? md : M;
+  }
+  const int ntm = (M + BM - 1) / BM, ntn = p.N / BN;
+  const int nk = (p.K / BK) / p.split_k;
+  const int per_split = ntm * ntn;
+  const int total = per_split * p.split_k;
+  const bool one_shot = ((int)gridDim.x == total);
+
+  // per-lane fragment read offsets (bytes inside a tile): row = base + (lane & 15), swizzle = lane & 7
+  const int frag_row = lane & 15;
+  const int frag_kc = lane >> 4;
+  const int swz = lane & 7;
+
+  for (int t0 = blockIdx.x; t0 < total; t0 += gridDim.x) {
+    const int t = one_shot ? xcd_remap(t0, total) : t0;
+    const int ks = t / per_split;
+    const int tt = t - ks * per_split;
+    int rt, ct;
+    if (ntm >= ntn) {
+      rt = tt / ntn;
+      ct = tt - rt * ntn;
+    } else {
+      ct = tt / ntm;
+      rt = tt - ct * ntm;
+    }
+    const int m0 = rt * BM, n0 = ct * BN;
+    const long k_begin = (long)ks * nk * BK;
+
+    // ---- staging addresses: each wave moves 32 rows of A and 32 rows of B per K tile (4 + 4 DMA ops)
+    const bf16* ga[4];
+    const bf16* gb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = wave * 32 + i * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ (r & 7);  // logical 16-byte chunk fetched into physical slot (lane & 7)
+      int ra = m0 + r;
+      ra = ra < M ? ra : M - 1;  // clamp: rows past M are computed on a duplicate row and never stored
+      ga[i] = p.A + (long)ra * p.lda + k_begin + c * 8;
+      gb[i] = p.B + (long)(n0 + r) * p.ldb + k_begin + c * 8;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage_glds = [&](int kt, int buf) {
+      char* sa = smem + buf * STAGE_BYTES + wave * 32 * 128;
+      char* sb = sa + TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + (long)kt * BK),
+                                         (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + (long)kt * BK),
+                                         (__attribute__((address_space(3))) void*)(sb + i * 1024), 16, 0, 0);
+      }
+    };
+    bf16x8 ra_[4], rb_[4];
+    auto stage_load_regs = [&](int kt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra_[i] = *(const bf16x8*)(ga[i] + (long)kt * BK);
+        rb_[i] = *(const bf16x8*)(gb[i] + (long)kt * BK);
+      }
+    };
+    auto stage_store_regs = [&](int buf) {
+      char* sa = smem + buf * STAGE_BYTES + wave * 32 * 128 + lane * 16;
+      char* sb = sa + TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *(bf16x8*)(sa + i * 1024) = ra_[i];
+        *(bf16x8*)(sb + i * 1024) = rb_[i];
+      }
+    };
+
+    auto compute = [&](int buf) {
+      const char* sa = smem + buf * STAGE_BYTES + (wm * 64 + frag_row) * 128;
+      const char* sb = smem + buf * STAGE_BYTES + TILE_BYTES + (wn * 64 + frag_row) * 128;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int coff = ((s * 4 + frag_kc) ^ swz) * 16;
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(sa + i * 16 * 128 + coff);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(sb + j * 16 * 128 + coff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (OUT_MODE == 2)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            else  // swapped: D[n][m], so a lane ends up with 4 consecutive output columns of one row
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+          }
+      }
+    };
+
+    __syncthreads();  // previous tile's epilogue / fragment reads are done before restaging
+    if (GLDS) {
+      stage_glds(0, 0);
+      for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage_glds(kt + 1, (kt + 1) & 1);
+        compute(kt & 1);
+      }
+    } else {
+      stage_load_regs(0);
+      stage_store_regs(0);
+      for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        if (kt + 1 < nk) stage_load_regs(kt + 1);
+        compute(kt & 1);
+        if (kt + 1 < nk) stage_store_regs((kt + 1) & 1);
+      }
+    }
+
+    // ---------------- epilogue (straight from the accumulators) ----------------
+    const int flags = p.flags;
+    if (OUT_MODE == 2) {
+      // standard orientation: acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane>>4)*4 + r][n0 + wn*64 + j*16 + (lane&15)]
+      float* C = (float*)p.C;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+          if (m < M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+              atomicAdd(C + (long)m * p.ldc + n, acc[i][j][r] * p.alpha);
+            }
+          }
+        }
+    } else {
+      // swapped: acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)][n0 + wn*64 + j*16 + (lane>>4)*4 + r]
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+          f32x4 v = acc[i][j] * p.alpha;
+          if (flags & STONK_EPI_BIAS) v += *(const f32x4*)(p.bias + n);
+          if (flags & STONK_EPI_SAVE_PREACT) {
+            bf16x4 u = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *(bf16x4*)(p.aux + (long)m * p.ldaux + n) = u;
+          }
+          if (flags & STONK_EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+          }
+          if (flags & STONK_EPI_GELU_BWD) {
+            const bf16x4 u = *(const bf16x4*)(p.aux + (long)m * p.ldaux + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)u[r]);
+          }
+          if (flags & STONK_EPI_DROPOUT) {
+            const uint32_t e = (uint32_t)((long)m * p.N + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              v[r] = stonk_keep(e + r, p.seed, p.drop_thr24) ? v[r] * p.drop_scale : 0.f;
+          }
+          if (flags & STONK_EPI_RESID) {
+            const bf16x4 rr = *(const bf16x4*)(p.resid + (long)m * p.ldr + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+          }
+          if (OUT_MODE == 0) {
+            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+          } else {
+            *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int OUT_MODE, bool GLDS>
+int launch(const GemmArgs& a, int grid, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<OUT_MODE, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        GEMM_LDS);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<OUT_MODE, GLDS>), dim3(grid), dim3(256), GEMM_LDS, st, a);
+  return stonk_launch_status();
+}
+
+}  // namespace
+
+extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                  int M, int N, int K, int flags, const float* bias, const void* resid,
+                                  int64_t ldr, void* aux, int64_t ldaux, float alpha, int split_k,
+                                  const int* m_dev, float drop_p, uint32_t seed, void* stream) {
+  STONK_CHECK_ARG(A && B && C, STONK_EINVAL);
+  STONK_CHECK_ARG(M >= 0 && N > 0 && K > 0, STONK_ESHAPE);
+  STONK_CHECK_ARG(N % BN == 0 && K % BK == 0, STONK_ESHAPE);
+  STONK_CHECK_ARG(split_k >= 1 && (K / BK) % split_k == 0, STONK_ESHAPE);
+  STONK_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, STONK_EALIGN);
+  STONK_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), STONK_EALIGN);
+  const int out_mode = flags & STONK_EPI_OUT_MASK;
+  STONK_CHECK_ARG(out_mode <= 2, STONK_EINVAL);
+  STONK_CHECK_ARG(split_k == 1 || out_mode == STONK_EPI_OUT_F32_ATOMIC, STONK_EINVAL);
+  if (flags & STONK_EPI_BIAS) STONK_CHECK_ARG(bias && ((uintptr_t)bias % 16 == 0), STONK_EINVAL);
+  if (flags & STONK_EPI_RESID) STONK_CHECK_ARG(resid && ldr % 4 == 0, STONK_EINVAL);
+  if (flags & (STONK_EPI_SAVE_PREACT | STONK_EPI_GELU_BWD)) STONK_CHECK_ARG(aux && ldaux % 4 == 0, STONK_EINVAL);
+  if (flags & STONK_EPI_DROPOUT) STONK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, STONK_EINVAL);
+  if (M == 0) return STONK_OK;
+
+  GemmArgs a;
+  a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C;
+  a.bias = bias; a.resid = (const bf16*)resid; a.aux = (bf16*)aux; a.m_dev = m_dev;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldaux = ldaux;
+  a.M = M; a.N = N; a.K = K; a.flags = flags; a.alpha = alpha; a.split_k = split_k;
+  a.drop_thr24 = stonk_drop_thr24(drop_p);
+  a.drop_scale = 1.0f / (1.0f - drop_p);
+  a.seed = seed;
+
+  const long tiles = (long)((M + BM - 1) / BM) * (N / BN) * split_k;
+  // with a device-side row count the grid is capped and blocks walk the tiles that exist at run time
+  const long cap = m_dev ? 4096 : tiles;
+  const int grid = (int)(tiles < cap ? tiles : cap);
+  hipStream_t st = (hipStream_t)stream;
+  const bool glds = !(flags & STONK_EPI_DEBUG_REGSTAGE);
+  switch (out_mode) {
+    case STONK_EPI_OUT_BF16: return glds ? launch<0, true>(a, grid, st) : launch<0, false>(a, grid, st);
+    case STONK_EPI_OUT_F32: return glds ? launch<1, true>(a, grid, st) : launch<1, false>(a, grid, st);
+    default: return glds ? launch<2, true>(a, grid, st) : launch<2, false>(a, grid, st);
+  }
+}
+
+extern "C" int stonk_abi_version(void) { return 1; }

@@ -1,0 +1,429 @@
+// LayerNorm (forward / backward) and the two embedding front-ends of the STonKGs step, as wavefront-
+// reduction kernels: one 64-lane wave owns one row, each lane holds 16-byte chunks of it in registers,
+// reductions are xor-shuffles across the wave, nothing goes through LDS except the dgamma/dbeta
+// block reduction. HBM-bound by construction (one read, one write per element).
+//
+// Replaces: nn.LayerNorm(eps=1e-12) in hf:models/bert/modeling_bert.py BertEmbeddings :98-108,
+// BertSelfOutput :289-293, BertOutput :347-351, BertPredictionHeadTransform :476-480; the KG gather +
+// concat + cast of ref:src/stonkgs/models/stonkgs_model.py:182-200 (K2/K3 in SURVEY.md section 2.3).
+#include "common.h"
+#include "stonk_flags.h"
+
+namespace {
+
+template <int CPL>
+struct RowRegs {
+  float v[CPL][8];
+};
+
+template <int CPL>
+__device__ __forceinline__ void load_bf16_row(const bf16* row, int nch, int lane, RowRegs<CPL>& r) {
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const bf16x8 x = *(const bf16x8*)(row + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[i][j] = (float)x[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
+    }
+  }
+}
+template <int CPL>
+__device__ __forceinline__ void load_f32_row(const float* row, int nch, int lane, RowRegs<CPL>& r) {
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const f32x4 a = *(const f32x4*)(row + c * 8);
+      const f32x4 b = *(const f32x4*)(row + c * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r.v[i][j] = a[j];
+        r.v[i][4 + j] = b[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
+    }
+  }
+}
+template <int CPL>
+__device__ __forceinline__ void add_f32_row(const float* row, int nch, int lane, RowRegs<CPL>& r) {
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const f32x4 a = *(const f32x4*)(row + c * 8);
+      const f32x4 b = *(const f32x4*)(row + c * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r.v[i][j] += a[j];
+        r.v[i][4 + j] += b[j];
+      }
+    }
+  }
+}
+template <int CPL>
+__device__ __forceinline__ void store_bf16_row(bf16* row, int nch, int lane, const RowRegs<CPL>& r) {
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)r.v[i][j];
+      *(bf16x8*)(row + c * 8) = o;
+    }
+  }
+}
+
+// two-pass (mean, then centred variance) statistics in fp32, as torch's native_layer_norm computes them
+template <int CPL>
+__device__ __forceinline__ void row_stats(const RowRegs<CPL>& r, int nch, int lane, int H, float eps, float& mean,
+                                          float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += r.v[i][j];
+  mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = r.v[i][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float var = wave_sum(q) / (float)H;
+  rstd = rsqrtf(var + eps);
+}
+
+// y = (x - mean) * rstd * gamma + beta, optional inverted dropout on y
+template <int CPL>
+__device__ __forceinline__ void normalize_store(RowRegs<CPL>& r, int nch, int lane, float mean, float rstd,
+                                                const float* gamma, const float* beta, bf16* yrow, long row_idx, int H,
+                                                bool drop, uint32_t thr24, float dscale, uint32_t seed) {
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const f32x4 g0 = *(const f32x4*)(gamma + c * 8), g1 = *(const f32x4*)(gamma + c * 8 + 4);
+      const f32x4 b0 = *(const f32x4*)(beta + c * 8), b1 = *(const f32x4*)(beta + c * 8 + 4);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float g = j < 4 ? g0[j] : g1[j - 4];
+        const float b = j < 4 ? b0[j] : b1[j - 4];
+        float y = (r.v[i][j] - mean) * rstd * g + b;
+        if (drop) y = stonk_keep((uint32_t)(row_idx * H + c * 8 + j), seed, thr24) ? y * dscale : 0.f;
+        o[j] = (bf16)y;
+      }
+      *(bf16x8*)(yrow + c * 8) = o;
+    }
+  }
+}
+
+template <int CPL>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            long rows, int H, float eps, int flags, uint32_t thr24,
+                                                            float dscale, uint32_t seed) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = H >> 3;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    RowRegs<CPL> r;
+    load_bf16_row<CPL>(x + row * H, nch, lane, r);
+    float mean, rstd;
+    row_stats<CPL>(r, nch, lane, H, eps, mean, rstd);
+    if (lane == 0 && mean_out) {
+      mean_out[row] = mean;
+      rstd_out[row] = rstd;
+    }
+    normalize_store<CPL>(r, nch, lane, mean, rstd, gamma, beta, y + row * H, row, H, flags & STONK_LN_DROPOUT, thr24,
+                         dscale, seed);
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dgamma += sum dy * xhat; dbeta += sum dy
+template <int CPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const bf16* __restrict__ dy, const bf16* __restrict__ x, const float* __restrict__ mean_in,
+    const float* __restrict__ rstd_in, const float* __restrict__ gamma, bf16* __restrict__ dx,
+    bf16* __restrict__ dx_drop, float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int H, int flags,
+    uint32_t thr24_in, float dscale_in, uint32_t seed_in, uint32_t thr24_out, float dscale_out, uint32_t seed_out) {
+  extern __shared__ __attribute__((aligned(16))) float sred[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = H >> 3;
+  float ag[CPL][8], ab[CPL][8];
+#pragma unroll
+  for (int i = 0; i < CPL; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ag[i][j] = ab[i][j] = 0.f;
+
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    RowRegs<CPL> rx, rd;
+    load_bf16_row<CPL>(x + row * H, nch, lane, rx);
+    load_bf16_row<CPL>(dy + row * H, nch, lane, rd);
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const f32x4 g0 = *(const f32x4*)(gamma + c * 8), g1 = *(const f32x4*)(gamma + c * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float d = rd.v[i][j];
+          if (flags & STONK_LN_DROPOUT)
+            d = stonk_keep((uint32_t)(row * H + c * 8 + j), seed_in, thr24_in) ? d * dscale_in : 0.f;
+          const float xh = (rx.v[i][j] - mean) * rstd;
+          ag[i][j] += d * xh;
+          ab[i][j] += d;
+          const float g = d * (j < 4 ? g0[j] : g1[j - 4]);
+          rx.v[i][j] = xh;
+          rd.v[i][j] = g;
+          s1 += g;
+          s2 += g * xh;
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)H, c2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        bf16x8 o, od;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = rstd * (rd.v[i][j] - c1 - rx.v[i][j] * c2);
+          o[j] = (bf16)v;
+          if (dx_drop)
+            od[j] = (bf16)(stonk_keep((uint32_t)(row * H + c * 8 + j), seed_out, thr24_out) ? v * dscale_out : 0.f);
+        }
+        *(bf16x8*)(dx + row * H + c * 8) = o;
+        if (dx_drop) *(bf16x8*)(dx_drop + row * H + c * 8) = od;
+      }
+    }
+  }
+  // block reduction of the per-wave column partials, then one atomic per column per block
+  if (dgamma) {
+    float* sg = sred;          // [4][H]
+    float* sb = sred + 4 * H;  // [4][H]
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          sg[wave * H + c * 8 + j] = ag[i][j];
+          sb[wave * H + c * 8 + j] = ab[i][j];
+        }
+      }
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += 256) {
+      const float g = sg[col] + sg[H + col] + sg[2 * H + col] + sg[3 * H + col];
+      const float b = sb[col] + sb[H + col] + sb[2 * H + col] + sb[3 * H + col];
+      atomicAdd(dgamma + col, g);
+      atomicAdd(dbeta + col, b);
+    }
+  }
+}
+
+// K2+K3: gather / concat / position + token-type add / LayerNorm in one pass.
+//  text half  (s <  half): source row = frozen-backbone hidden state (bf16)
+//  entity half(s >= half): source row = kg_table[input_ids[b,s]] (fp32; rows 100/102/103 hold the LM
+//                          special-token vectors, quirks Q1/Q2 of SURVEY.md section 8)
+template <int CPL>
+__global__ __launch_bounds__(256) void joint_embed_ln_kernel(
+    const long* __restrict__ input_ids, const long* __restrict__ token_type_ids, const bf16* __restrict__ text_hidden,
+    const float* __restrict__ kg_table, const float* __restrict__ pos_emb, const float* __restrict__ type_emb,
+    const float* __restrict__ gamma, const float* __restrict__ beta, bf16* __restrict__ sum_out, bf16* __restrict__ y,
+    float* __restrict__ mean_out, float* __restrict__ rstd_out, int B, int S, int half, int H, long kg_rows,
+    int type_rows, float eps, int flags, uint32_t thr24, float dscale, uint32_t seed, int* __restrict__ err) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = H >> 3;
+  const long rows = (long)B * S;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const int b = (int)(row / S), s = (int)(row - (long)b * S);
+    RowRegs<CPL> r;
+    if (s < half) {
+      load_bf16_row<CPL>(text_hidden + ((long)b * half + s) * H, nch, lane, r);
+    } else {
+      long id = input_ids[row];
+      if (id < 0 || id >= kg_rows) {  // the reference raises KeyError here (stonkgs_model.py:185)
+        if (lane == 0) atomicOr(err, 1);
+        id = 0;
+      }
+      load_f32_row<CPL>(kg_table + id * H, nch, lane, r);
+    }
+    long tt = token_type_ids ? token_type_ids[row] : 0;
+    if (tt < 0 || tt >= type_rows) {
+      if (lane == 0) atomicOr(err, 2);
+      tt = 0;
+    }
+    add_f32_row<CPL>(pos_emb + (long)s * H, nch, lane, r);
+    add_f32_row<CPL>(type_emb + tt * H, nch, lane, r);
+    if (sum_out) store_bf16_row<CPL>(sum_out + row * H, nch, lane, r);
+    float mean, rstd;
+    row_stats<CPL>(r, nch, lane, H, eps, mean, rstd);
+    if (lane == 0 && mean_out) {
+      mean_out[row] = mean;
+      rstd_out[row] = rstd;
+    }
+    normalize_store<CPL>(r, nch, lane, mean, rstd, gamma, beta, y + row * H, row, H, flags & STONK_LN_DROPOUT, thr24,
+                         dscale, seed);
+  }
+}
+
+// Frozen LM backbone front-end: word_emb[ids] + pos_emb + type_emb[0] -> LayerNorm (hf BertEmbeddings :98-108)
+template <int CPL>
+__global__ __launch_bounds__(256) void text_embed_ln_kernel(const long* __restrict__ input_ids, long ld_ids,
+                                                            const float* __restrict__ word_emb,
+                                                            const float* __restrict__ pos_emb,
+                                                            const float* __restrict__ type_emb,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16* __restrict__ y, int B,
+                                                            int S, int H, long vocab, float eps, int flags,
+                                                            uint32_t thr24, float dscale, uint32_t seed,
+                                                            int* __restrict__ err) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = H >> 3;
+  const long rows = (long)B * S;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const int b = (int)(row / S), s = (int)(row - (long)b * S);
+    long id = input_ids[(long)b * ld_ids + s];
+    if (id < 0 || id >= vocab) {
+      if (lane == 0) atomicOr(err, 4);
+      id = 0;
+    }
+    RowRegs<CPL> r;
+    load_f32_row<CPL>(word_emb + id * H, nch, lane, r);
+    add_f32_row<CPL>(pos_emb + (long)s * H, nch, lane, r);
+    add_f32_row<CPL>(type_emb, nch, lane, r);
+    float mean, rstd;
+    row_stats<CPL>(r, nch, lane, H, eps, mean, rstd);
+    normalize_store<CPL>(r, nch, lane, mean, rstd, gamma, beta, y + row * H, row, H, flags & STONK_LN_DROPOUT, thr24,
+                         dscale, seed);
+  }
+}
+
+// d(position_embeddings)[s] += sum_b dx[b,s,:];  d(token_type_embeddings)[t] += sum_{(b,s): tt==t} dx[b,s,:]
+__global__ __launch_bounds__(256) void embed_grad_kernel(const bf16* __restrict__ dx,
+                                                         const long* __restrict__ token_type_ids,
+                                                         float* __restrict__ dpos, float* __restrict__ dtype, int B,
+                                                         int S, int H, int type_rows) {
+  const int s = blockIdx.x;
+  for (int col = threadIdx.x; col < H; col += blockDim.x) {
+    float accp = 0.f, t0 = 0.f, t1 = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const long row = (long)b * S + s;
+      const float v = (float)dx[row * H + col];
+      accp += v;
+      const long tt = token_type_ids ? token_type_ids[row] : 0;
+      if (tt == 0) t0 += v;
+      else if (tt == 1) t1 += v;
+    }
+    dpos[(long)s * H + col] += accp;  // one block per position: no race
+    atomicAdd(dtype + col, t0);
+    if (type_rows > 1) atomicAdd(dtype + H + col, t1);
+  }
+}
+
+inline int ln_grid(long rows) {
+  long g = (rows + 3) / 4;
+  return (int)(g < 2048 ? (g > 0 ? g : 1) : 2048);
+}
+
+}  // namespace
+
+#define LN_DISPATCH(H, CALL)                     \
+  if ((H) <= 1024) { constexpr int CPL = 2; CALL; } \
+  else if ((H) <= 2048) { constexpr int CPL = 4; CALL; } \
+  else { constexpr int CPL = 8; CALL; }
+
+extern "C" int stonk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                   float* rstd, int64_t rows, int H, float eps, int flags, float drop_p,
+                                   uint32_t seed, void* stream) {
+  STONK_CHECK_ARG(x && gamma && beta && y, STONK_EINVAL);
+  STONK_CHECK_ARG(rows >= 0 && H > 0 && H % 8 == 0 && H <= 4096, STONK_ESHAPE);
+  STONK_CHECK_ARG((mean == nullptr) == (rstd == nullptr), STONK_EINVAL);
+  if (rows == 0) return STONK_OK;
+  const uint32_t thr = stonk_drop_thr24(drop_p);
+  const float ds = 1.f / (1.f - drop_p);
+  LN_DISPATCH(H, hipLaunchKernelGGL((layernorm_fwd_kernel<CPL>), dim3(ln_grid(rows)), dim3(256), 0,
+                                    (hipStream_t)stream, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, (long)rows,
+                                    H, eps, flags, thr, ds, seed));
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd,
+                                   const float* gamma, void* dx, void* dx_drop, float* dgamma, float* dbeta,
+                                   int64_t rows, int H, int flags, float drop_p_in, uint32_t seed_in,
+                                   float drop_p_out, uint32_t seed_out, void* stream) {
+  STONK_CHECK_ARG(dy && x && mean && rstd && gamma && dx, STONK_EINVAL);
+  STONK_CHECK_ARG(rows >= 0 && H > 0 && H % 8 == 0 && H <= 4096, STONK_ESHAPE);
+  STONK_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), STONK_EINVAL);
+  if (rows == 0) return STONK_OK;
+  const size_t lds = dgamma ? (size_t)8 * H * sizeof(float) : 0;
+  LN_DISPATCH(H, hipLaunchKernelGGL((layernorm_bwd_kernel<CPL>), dim3(ln_grid(rows) < 1024 ? ln_grid(rows) : 1024),
+                                    dim3(256), lds, (hipStream_t)stream, (const bf16*)dy, (const bf16*)x, mean, rstd,
+                                    gamma, (bf16*)dx, (bf16*)dx_drop, dgamma, dbeta, (long)rows, H, flags,
+                                    stonk_drop_thr24(drop_p_in), 1.f / (1.f - drop_p_in), seed_in,
+                                    stonk_drop_thr24(drop_p_out), 1.f / (1.f - drop_p_out), seed_out));
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_joint_embed_ln_fwd(const int64_t* input_ids, const int64_t* token_type_ids,
+                                        const void* text_hidden, const float* kg_table, const float* pos_emb,
+                                        const float* type_emb, const float* gamma, const float* beta, void* sum_out,
+                                        void* y, float* mean, float* rstd, int B, int S, int half, int H,
+                                        int64_t kg_rows, int type_rows, float eps, int flags, float drop_p,
+                                        uint32_t seed, int* err_flag, void* stream) {
+  STONK_CHECK_ARG(input_ids && text_hidden && kg_table && pos_emb && type_emb && gamma && beta && y && err_flag,
+                  STONK_EINVAL);
+  STONK_CHECK_ARG(B >= 0 && S > 0 && half >= 0 && half <= S && H > 0 && H % 8 == 0 && H <= 4096, STONK_ESHAPE);
+  STONK_CHECK_ARG(kg_rows > 0 && type_rows > 0, STONK_ESHAPE);
+  if (B == 0) return STONK_OK;
+  const long rows = (long)B * S;
+  LN_DISPATCH(H, hipLaunchKernelGGL((joint_embed_ln_kernel<CPL>), dim3(ln_grid(rows)), dim3(256), 0,
+                                    (hipStream_t)stream, (const long*)input_ids, (const long*)token_type_ids,
+                                    (const bf16*)text_hidden, kg_table, pos_emb, type_emb, gamma, beta,
+                                    (bf16*)sum_out, (bf16*)y, mean, rstd, B, S, half, H, (long)kg_rows, type_rows, eps,
+                                    flags, stonk_drop_thr24(drop_p), 1.f / (1.f - drop_p), seed, err_flag));
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_text_embed_ln_fwd(const int64_t* input_ids, int64_t ld_ids, const float* word_emb,
+                                       const float* pos_emb, const float* type_emb, const float* gamma,
+                                       const float* beta, void* y, int B, int S, int H, int64_t vocab, float eps,
+                                       int flags, float drop_p, uint32_t seed, int* err_flag, void* stream) {
+  STONK_CHECK_ARG(input_ids && word_emb && pos_emb && type_emb && gamma && beta && y && err_flag, STONK_EINVAL);
+  STONK_CHECK_ARG(B >= 0 && S > 0 && ld_ids >= S && H > 0 && H % 8 == 0 && H <= 4096 && vocab > 0, STONK_ESHAPE);
+  if (B == 0) return STONK_OK;
+  const long rows = (long)B * S;
+  LN_DISPATCH(H, hipLaunchKernelGGL((text_embed_ln_kernel<CPL>), dim3(ln_grid(rows)), dim3(256), 0,
+                                    (hipStream_t)stream, (const long*)input_ids, (long)ld_ids, word_emb, pos_emb,
+                                    type_emb, gamma, beta, (bf16*)y, B, S, H, (long)vocab, eps, flags,
+                                    stonk_drop_thr24(drop_p), 1.f / (1.f - drop_p), seed, err_flag));
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_embed_grad(const void* dx, const int64_t* token_type_ids, float* dpos, float* dtype, int B, int S,
+                                int H, int type_rows, void* stream) {
+  STONK_CHECK_ARG(dx && dpos && dtype, STONK_EINVAL);
+  STONK_CHECK_ARG(B >= 0 && S > 0 && H > 0 && type_rows >= 1, STONK_ESHAPE);
+  if (B == 0) return STONK_OK;
+  hipLaunchKernelGGL(embed_grad_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, (const bf16*)dx,
+                     (const long*)token_type_ids, dpos, dtype, B, S, H, type_rows);
+  return stonk_launch_status();
+}

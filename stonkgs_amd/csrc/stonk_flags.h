@@ -1,0 +1,16 @@
+// Epilogue / mode flags shared by the HIP sources and include/stonk_hip.h (which includes this file).
+#pragma once
+// --- stonk_gemm_nt_bf16 `flags` ---
+#define STONK_EPI_OUT_BF16 0        /* C is bf16 */
+#define STONK_EPI_OUT_F32 1         /* C is fp32 */
+#define STONK_EPI_OUT_F32_ATOMIC 2  /* C (fp32) += result, via global_atomic_add_f32; required for split_k > 1 */
+#define STONK_EPI_OUT_MASK 3
+#define STONK_EPI_BIAS (1 << 2)         /* + bias[n] (fp32) */
+#define STONK_EPI_GELU (1 << 3)         /* exact erf GELU */
+#define STONK_EPI_RESID (1 << 4)        /* + resid[m][n] (bf16), after activation/dropout */
+#define STONK_EPI_SAVE_PREACT (1 << 5)  /* aux[m][n] (bf16) = value before the activation */
+#define STONK_EPI_GELU_BWD (1 << 6)     /* result *= gelu'(aux[m][n]) */
+#define STONK_EPI_DROPOUT (1 << 7)      /* inverted dropout (drop_p, seed) before the residual add */
+#define STONK_EPI_DEBUG_REGSTAGE (1 << 16) /* A/B test: register staging instead of LDS-DMA */
+// --- stonk_layernorm_* `flags` ---
+#define STONK_LN_DROPOUT (1 << 0)

@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hip():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from stonkgs_amd import _hip
+
+    _hip.lib()  # raises if the extension is missing: GPU tests never fall back
+    return _hip

@@ -1,0 +1,102 @@
+"""GPU parity: bf16 MFMA GEMM (C-ABI stonk_gemm_nt_bf16) against torch fp32 matmul on the same bf16 inputs."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(hip, A, B, out_dtype=torch.bfloat16, M=None, flags=0, bias=None, resid=None, aux=None, alpha=1.0,
+          split_k=1, C=None, m_dev=None, drop_p=0.0, seed=0):
+    M = A.shape[0] if M is None else M
+    N, K = B.shape
+    if C is None:
+        C = torch.empty(M, N, device=A.device, dtype=out_dtype)
+    hip.call("stonk_gemm_nt_bf16", hip.ptr(A), A.stride(0), hip.ptr(B), B.stride(0), hip.ptr(C), C.stride(0), M, N, K,
+             flags, hip.ptr(bias), hip.ptr(resid), 0 if resid is None else resid.stride(0), hip.ptr(aux),
+             0 if aux is None else aux.stride(0), alpha, split_k, hip.ptr(m_dev), drop_p, seed, hip.stream_ptr())
+    return C
+
+
+def _rand(shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, device="cuda", generator=g) * scale).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("regstage", [False, True])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (1000, 768, 3072), (77, 2304, 768)])
+def test_gemm_plain_bf16_and_f32(hip, M, N, K, regstage):
+    A, B = _rand((M, K), seed=1), _rand((N, K), seed=2)
+    ref = A.float() @ B.float().t()
+    dbg = hip.EPI_DEBUG_REGSTAGE if regstage else 0
+    out32 = _gemm(hip, A, B, torch.float32, flags=hip.EPI_OUT_F32 | dbg)
+    torch.cuda.synchronize()
+    err = (out32 - ref).abs().max().item()
+    assert err <= 1e-3 * math.sqrt(K), f"fp32-out max err {err}"
+    out16 = _gemm(hip, A, B, torch.bfloat16, flags=hip.EPI_OUT_BF16 | dbg)
+    torch.testing.assert_close(out16.float(), ref, rtol=1.6e-2, atol=1e-2 * math.sqrt(K) / 8)
+
+
+def test_gemm_asymmetric_identity(hip):
+    """A = I with an asymmetric B catches a transposed C write (guide section 3)."""
+    K = 128
+    A = torch.eye(K, device="cuda", dtype=torch.bfloat16)
+    B = (torch.arange(256 * K, device="cuda").reshape(256, K) % 251).to(torch.bfloat16)
+    out = _gemm(hip, A, B, torch.float32, flags=hip.EPI_OUT_F32)
+    torch.testing.assert_close(out, B.float().t().contiguous(), rtol=0, atol=0)
+
+
+def test_gemm_epilogues(hip):
+    M, N, K = 300, 256, 192
+    A, B = _rand((M, K), 0.5, 3), _rand((N, K), 0.5, 4)
+    bias = torch.randn(N, device="cuda")
+    resid = _rand((M, N), 1.0, 5)
+    pre = A.float() @ B.float().t() + bias
+    # bias + gelu + saved pre-activation
+    aux = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    out = _gemm(hip, A, B, flags=hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT, bias=bias, aux=aux)
+    torch.testing.assert_close(aux.float(), pre, rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(out.float(), torch.nn.functional.gelu(pre), rtol=1e-2, atol=2e-2)
+    # bias + residual
+    out = _gemm(hip, A, B, flags=hip.EPI_BIAS | hip.EPI_RESID, bias=bias, resid=resid)
+    torch.testing.assert_close(out.float(), pre + resid.float(), rtol=1e-2, atol=3e-2)
+    # gelu backward: result * gelu'(aux)
+    u = _rand((M, N), 1.0, 6)
+    out = _gemm(hip, A, B, flags=hip.EPI_GELU_BWD, aux=u)
+    uf = u.float().requires_grad_(True)
+    (gp,) = torch.autograd.grad(torch.nn.functional.gelu(uf).sum(), uf)
+    torch.testing.assert_close(out.float(), (A.float() @ B.float().t()) * gp, rtol=1e-2, atol=3e-2)
+
+
+def test_gemm_splitk_atomic_accumulates(hip):
+    M, N, K = 256, 128, 2048
+    A, B = _rand((M, K), 0.3, 7), _rand((N, K), 0.3, 8)
+    C = torch.ones(M, N, device="cuda")
+    _gemm(hip, A, B, flags=hip.EPI_OUT_F32_ATOMIC, split_k=8, C=C)
+    torch.testing.assert_close(C, 1.0 + A.float() @ B.float().t(), rtol=1e-4, atol=1e-3)
+
+
+def test_gemm_device_row_count_and_dropout(hip):
+    M, N, K = 1024, 256, 128
+    A, B = _rand((M, K), 0.5, 9), _rand((N, K), 0.5, 10)
+    m_dev = torch.tensor([333], device="cuda", dtype=torch.int32)
+    C = torch.full((M, N), -7.0, device="cuda")
+    _gemm(hip, A, B, flags=hip.EPI_OUT_F32, C=C, m_dev=m_dev)
+    ref = A.float() @ B.float().t()
+    torch.testing.assert_close(C[:333], ref[:333], rtol=1e-4, atol=1e-3)
+    assert (C[333:] == -7.0).all()  # rows past the device-side count are never written
+    # dropout: keep-rate and scaling
+    out = _gemm(hip, A, B, torch.float32, flags=hip.EPI_OUT_F32 | hip.EPI_DROPOUT, drop_p=0.1, seed=123)
+    kept = out != 0
+    rate = 1.0 - kept.float().mean().item()
+    assert abs(rate - 0.1) < 0.01, rate
+    torch.testing.assert_close(out[kept], (ref / 0.9)[kept], rtol=1e-4, atol=1e-3)
+    out2 = _gemm(hip, A, B, torch.float32, flags=hip.EPI_OUT_F32 | hip.EPI_DROPOUT, drop_p=0.1, seed=123)
+    assert torch.equal(out, out2)  # same (seed, index) -> same mask, bit for bit
+
+
+def test_gemm_bad_arguments(hip):
+    A, B = _rand((128, 64)), _rand((100, 64))
+    with pytest.raises(hip.StonkHipError):
+        _gemm(hip, A, B)  # N not a multiple of 128

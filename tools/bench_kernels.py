@@ -1,0 +1,76 @@
+"""Micro-benchmarks of individual C-ABI kernels on one MI355X (development aid, not the judged bench)."""
+import sys
+import os
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stonkgs_amd import _hip as hip  # noqa: E402
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def bench_gemm():
+    shapes = [(32768, 2304, 768), (32768, 768, 768), (32768, 3072, 768), (32768, 768, 3072), (16384, 2304, 768),
+              (4096, 4096, 4096), (8192, 8192, 8192)]
+    for M, N, K in shapes:
+        A = (torch.randn(M, K, device="cuda")).to(torch.bfloat16)
+        B = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
+        C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        for name, dbg in (("glds", 0), ("regstage", hip.EPI_DEBUG_REGSTAGE)):
+            def f():
+                hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, M, N, K, dbg, 0, 0, 0, 0, 0,
+                         1.0, 1, 0, 0.0, 0, hip.stream_ptr())
+            t = timeit(f)
+            print(f"gemm {M}x{N}x{K} {name}: {t*1e6:.1f} us  {2*M*N*K/t/1e12:.1f} TF/s", flush=True)
+        t = timeit(lambda: torch.matmul(A, B.t()))
+        print(f"gemm {M}x{N}x{K} torch(hipBLASLt): {t*1e6:.1f} us  {2*M*N*K/t/1e12:.1f} TF/s", flush=True)
+    # wgrad-shaped: small output, long K, split-K atomics
+    for Mo, No, K, sk in [(768, 768, 32768, 8), (768, 768, 32768, 16), (3072, 768, 32768, 4), (768, 3072, 32768, 4),
+                          (2304, 768, 32768, 4)]:
+        A = torch.randn(Mo, K, device="cuda").to(torch.bfloat16)
+        B = torch.randn(No, K, device="cuda").to(torch.bfloat16)
+        C = torch.zeros(Mo, No, device="cuda")
+        def f():
+            hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), No, Mo, No, K,
+                     hip.EPI_OUT_F32_ATOMIC, 0, 0, 0, 0, 0, 1.0, sk, 0, 0.0, 0, hip.stream_ptr())
+        t = timeit(f)
+        print(f"wgrad {Mo}x{No}x{K} splitk={sk}: {t*1e6:.1f} us  {2*Mo*No*K/t/1e12:.1f} TF/s", flush=True)
+
+
+def bench_ln():
+    rows, H = 32768, 768
+    x = torch.randn(rows, H, device="cuda").to(torch.bfloat16)
+    y = torch.empty_like(x)
+    g = torch.ones(H, device="cuda")
+    b = torch.zeros(H, device="cuda")
+    mean = torch.empty(rows, device="cuda")
+    rstd = torch.empty(rows, device="cuda")
+    t = timeit(lambda: hip.call("stonk_layernorm_fwd", hip.ptr(x), hip.ptr(g), hip.ptr(b), hip.ptr(y), hip.ptr(mean),
+                                hip.ptr(rstd), rows, H, 1e-12, 0, 0.0, 0, hip.stream_ptr()))
+    print(f"layernorm_fwd {rows}x{H}: {t*1e6:.1f} us  {rows*H*4/t/1e9:.0f} GB/s", flush=True)
+    dx = torch.empty_like(x)
+    dg = torch.zeros(H, device="cuda")
+    db = torch.zeros(H, device="cuda")
+    t = timeit(lambda: hip.call("stonk_layernorm_bwd", hip.ptr(y), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(g),
+                                hip.ptr(dx), 0, hip.ptr(dg), hip.ptr(db), rows, H, 0, 0.0, 0, 0.0, 0, hip.stream_ptr()))
+    print(f"layernorm_bwd {rows}x{H}: {t*1e6:.1f} us  {rows*H*6/t/1e9:.0f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gemm", "ln"]
+    hip.lib()
+    for w in which:
+        globals()["bench_" + w]()

@@ -1,0 +1,138 @@
+/* stonk_hip.h - C ABI of libstonk_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the STonKGs
+ * pre-training hot path (STonKGsForPreTraining forward / backward / optimizer step).
+ *
+ * The reference (stonkgs v0.1.6-dev) has no FFI of its own: its hot path is a Python nn.Module whose
+ * arithmetic is issued by HuggingFace `modeling_bert` into torch ATen. This header is therefore the
+ * boundary a maintainer would bind (ctypes) to replace those ATen calls; every entry
+ * cites the reference / HF site it replaces ("ref:" = /root/reference, "hf:" = transformers).
+ *
+ * Conventions:
+ *  - plain pointers and sizes only; all pointers are DEVICE addresses unless stated; bf16 = 16-bit brain
+ *    float stored as uint16_t; "ld*" are row strides in ELEMENTS;
+ *  - every launcher is asynchronous on `stream` (a hipStream_t passed as void*), allocates nothing, keeps no
+ *    global state, never throws; it returns 0 on success, <0 for a rejected argument (STONK_E*), >0 for a
+ *    hipError_t raised by the launch;
+ *  - dropout masks are regenerated from (seed, element index) by a counter-based hash, never stored.
+ */
+#ifndef STONK_HIP_H
+#define STONK_HIP_H
+#include <stdint.h>
+#include "../stonkgs_amd/csrc/stonk_flags.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STONK_OK 0
+#define STONK_EINVAL (-1) /* null pointer / inconsistent argument */
+#define STONK_ESHAPE (-2) /* unsupported shape */
+#define STONK_EALIGN (-3) /* pointer or stride not aligned as required */
+
+int stonk_abi_version(void);
+
+/* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T), A/B bf16, fp32 accumulate on MFMA. N % 128 == 0, K % 64 == 0.
+ * `flags`: STONK_EPI_* (output type, bias, GELU, residual, saved pre-activation, GELU', dropout).
+ * m_dev / k_dev (nullable): effective M / K read from device memory at run time (label-sparse decoders).
+ * Replaces torch addmm/mm of hf:models/bert/modeling_bert.py:154-156 (Q,K,V), :289-293 (attn out), :334-337
+ * (FFN up + GELU), :347-351 (FFN down), :476-480 (head transform); ref:src/stonkgs/models/stonkgs_model.py:70-71
+ * (text / entity decoders) and their autograd backward. */
+int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                       int flags, const float* bias, const void* resid, int64_t ldr, void* aux, int64_t ldaux,
+                       float alpha, int split_k, const int* m_dev, const int* k_dev, float drop_p, uint32_t seed,
+                       void* stream);
+
+/* y = dropout(LayerNorm(x)); x,y bf16 [rows,H]; gamma/beta fp32; mean/rstd fp32 [rows] saved for backward.
+ * Replaces nn.LayerNorm(eps=1e-12) + nn.Dropout at hf:modeling_bert.py:106-107, :291-292, :349-350, :479. */
+int stonk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                        int64_t rows, int H, float eps, int flags, float drop_p, uint32_t seed, void* stream);
+
+/* dx = LayerNorm'(dy) (dy first masked by the forward's output dropout when STONK_LN_DROPOUT);
+ * dx_drop (nullable) = dropout-masked copy of dx for the branch that went through nn.Dropout before the residual
+ * add; dgamma/dbeta (fp32, nullable) are ACCUMULATED. Autograd backward of the sites above. */
+int stonk_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                        void* dx, void* dx_drop, float* dgamma, float* dbeta, int64_t rows, int H, int flags,
+                        float drop_p_in, uint32_t seed_in, float drop_p_out, uint32_t seed_out, void* stream);
+
+/* inputs_embeds + position + token-type embeddings -> LayerNorm -> dropout, in one pass:
+ *   row (b,s<half)  = text_hidden[b*half+s]          (frozen LM backbone output, bf16)
+ *   row (b,s>=half) = kg_table[input_ids[b,s]]       (fp32 node2vec table; ids 100/102/103 = LM special vectors)
+ * Replaces the Python gather loop, torch.stack/cat and the CPU fp32 round trip of
+ * ref:src/stonkgs/models/stonkgs_model.py:182-200 plus BertEmbeddings hf:modeling_bert.py:98-108.
+ * An id outside [0, kg_rows) sets bit 0 of *err_flag (the reference raises KeyError at :185). */
+int stonk_joint_embed_ln_fwd(const int64_t* input_ids, const int64_t* token_type_ids, const void* text_hidden,
+                             const float* kg_table, const float* pos_emb, const float* type_emb, const float* gamma,
+                             const float* beta, void* sum_out, void* y, float* mean, float* rstd, int B, int S,
+                             int half, int H, int64_t kg_rows, int type_rows, float eps, int flags, float drop_p,
+                             uint32_t seed, int* err_flag, void* stream);
+
+/* Frozen LM backbone embeddings: word_emb[input_ids[:, :S]] + pos + type[0] -> LayerNorm -> dropout.
+ * Replaces BertEmbeddings of `self.lm_backbone(input_ids[:, :half])`, ref:stonkgs_model.py:178. */
+int stonk_text_embed_ln_fwd(const int64_t* input_ids, int64_t ld_ids, const float* word_emb, const float* pos_emb,
+                            const float* type_emb, const float* gamma, const float* beta, void* y, int B, int S, int H,
+                            int64_t vocab, float eps, int flags, float drop_p, uint32_t seed, int* err_flag,
+                            void* stream);
+
+/* d(position_embeddings) and d(token_type_embeddings) from d(embedding sum) (bf16 [B*S,H]); accumulates. */
+int stonk_embed_grad(const void* dx, const int64_t* token_type_ids, float* dpos, float* dtype, int B, int S, int H,
+                     int type_rows, void* stream);
+
+/* Fused attention, head_dim 64, S % 128 == 0: out = dropout(softmax(q k^T * scale + mask)) v.
+ * q/k/v: column slices of the [T, 3H] projection (row stride ld), head h at columns h*64..; attention_mask int64
+ * [B,S] (0 = masked key) or NULL; lse fp32 [B,NH,S]. Replaces hf:modeling_bert.py:188-203 (eager :111-136). */
+int stonk_attention_fwd(const void* q, const void* k, const void* v, int64_t ld, const int64_t* attention_mask,
+                        void* out, int64_t ldo, float* lse, int B, int NH, int S, int D, float scale, float drop_p,
+                        uint32_t seed, void* stream);
+/* Backward of the above (recomputes P from lse; no atomics). delta_ws: fp32 [B,NH,S] scratch. */
+int stonk_attention_bwd(const void* q, const void* k, const void* v, int64_t ld, const int64_t* attention_mask,
+                        const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta_ws,
+                        void* dq, void* dk, int64_t ldd, void* dv, int B, int NH, int S, int D, float scale,
+                        float drop_p, uint32_t seed, void* stream);
+
+/* out[c][r] = in[r][c] (bf16). Rows >= *rows_dev (nullable) read as zero; colsum (nullable, fp32) += column sums
+ * of `in` (bias gradients). Feeds wgrad operands to stonk_gemm_nt_bf16. */
+int stonk_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int cols,
+                         float* colsum, const int* rows_dev, void* stream);
+int stonk_transpose_f32_to_bf16(const float* in, void* out, int64_t rows, int cols, int64_t ld_out, void* stream);
+int stonk_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+
+/* Labelled-row compaction for the MLM / ELM heads (labels != -100), count kept on the device.
+ * rows_out[i] = b*S + offset + pos of the i-th labelled position. Semantics of nn.CrossEntropyLoss(ignore_index
+ * =-100) at ref:stonkgs_model.py:229-240. */
+int stonk_label_compact(const int64_t* labels, int64_t n, int half, int S, int offset, int* rows_out, int* targets_out,
+                        int* count_out, void* stream);
+int stonk_gather_rows_bf16(const void* src, int64_t ld_src, const int* rows, const int* count_dev, void* dst,
+                           int64_t ld_dst, int cols, int64_t cap, void* stream);
+int stonk_scatter_rows_bf16(const void* src, int64_t ld_src, const int* rows, const int* count_dev, void* dst,
+                            int64_t ld_dst, int cols, void* stream);
+
+/* Per labelled row: loss_sum += logsumexp(logits[row,:ncols]) - logits[row,target];
+ * dlogits (bf16, nullable) = (softmax - onehot) * grad_scale / count. Bit 3 of *err_flag: target out of range. */
+int stonk_softmax_xent_fwd_bwd(const float* logits, int64_t ld, int ncols, int npad, const int* targets,
+                               const int* count_dev, float* loss_sum, void* dlogits, int64_t ld_d, float grad_scale,
+                               int* err_flag, void* stream);
+/* NSP loss (ref:stonkgs_model.py:241-243): loss_sum_cnt[0] += sum, [1] += number of labels. */
+int stonk_nsp_xent_fwd_bwd(const float* logits, const int64_t* labels, int B, int C, float* loss_sum_cnt, float* dlogits,
+                           float grad_scale, int* err_flag, void* stream);
+/* loss_out[0..3] = total, text MLM, entity MLM, NSP (ref:stonkgs_model.py:245). */
+int stonk_loss_finalize(const float* text_sum, const int* text_cnt, const float* ent_sum, const int* ent_cnt,
+                        const float* nsp_sum_cnt, float* loss_out, void* stream);
+
+/* BertPooler / NSP classifier on fp32 master weights (hf:modeling_bert.py:457-463, :523-527). */
+int stonk_small_linear_fwd(const void* x, int64_t ldx, const float* W, const float* bias, float* y, int M, int N, int K,
+                           int act, void* stream);
+int stonk_small_linear_bwd(const float* dy, const float* y, const void* x, int64_t ldx, const float* W, float* dW,
+                           float* db, float* dx_f32, void* dx_bf16_accum, int64_t ld_dxb, int M, int N, int K, int act,
+                           void* stream);
+
+/* Optimizer step pieces (hf:trainer.py:1780-1796 as driven by ref:src/stonkgs/models/stonkgs_pretraining.py:171-223):
+ * *out_accum += sum(x^2); fused clip_grad_norm_(max_grad_norm) + AdamW + bf16 weight refresh + grad zeroing. */
+int stonk_sumsq_f32(const float* x, int64_t n, float* out_accum, void* stream);
+int stonk_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, float bias_corr1, float bias_corr2, const float* gnorm_sq_dev,
+                     float max_grad_norm, float grad_scale, void* stream);
+int stonk_scale_f32(float* x, int64_t n, float s, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STONK_HIP_H */

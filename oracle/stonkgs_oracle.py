@@ -1,0 +1,333 @@
+"""CPU oracle for the STonKGs pre-training hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import this
+module; the product (``stonkgs_amd``) never does and has no CPU fallback.
+
+What it is: a plain-PyTorch fp32 restatement (no ``transformers`` import, no reference import) of
+  * ``STonKGsForPreTraining.forward``            ref:src/stonkgs/models/stonkgs_model.py:149-258
+  * ``STonKGsELMPredictionHead.forward``         ref:src/stonkgs/models/stonkgs_model.py:62-73
+  * the KG-backbone index space / special vectors ref:src/stonkgs/models/stonkgs_model.py:123-141
+  * the BERT arithmetic the reference delegates to HuggingFace (third-party dependency, NOT vendored under
+    /root/reference; reference pins ``transformers>=4.6.1`` in ref:setup.cfg:80, 5.15.0 installed here):
+    hf:models/bert/modeling_bert.py BertEmbeddings :98-108, BertSelfAttention :164-203 (eager :111-136),
+    BertSelfOutput :289-293, BertIntermediate :334-337, BertOutput :347-351, BertPooler :457-463,
+    BertPredictionHeadTransform :476-480, seq_relationship :523-527
+  * the optimizer step the reference's driver runs through HF ``Trainer``
+    (ref:src/stonkgs/models/stonkgs_pretraining.py:171-223 -> hf:trainer.py:1780-1796): clip_grad_norm_(1.0),
+    AdamW(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0), linear decay to 0 with no warm-up
+  * the offline masking that defines the batch schema
+    ref:src/stonkgs/data/indra_for_pretraining.py:33-77 (replace_mlm_tokens), :80-126 (NSP negatives).
+
+Pinning: the reference's own test-suite holds no vectors for this path, so the oracle is
+pinned against the reference ITSELF, imported in the authoring container by ``oracle/make_golden.py`` (reference
+``forward`` unmodified + HF BERT, local config, random weights); the resulting inputs/outputs are committed under
+``tests/golden/`` and ``tests/test_oracle_golden.py`` replays them without the reference.
+"""
+from __future__ import annotations
+
+import math
+import random
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class OracleConfig:
+    vocab_size: int = 28996
+    kg_vocab_size: int = 175094
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    max_position_embeddings: int = 512
+    type_vocab_size: int = 2
+    layer_norm_eps: float = 1e-12
+    # the LM backbone may be shaped differently from the trainable encoder only in depth / position count
+    backbone_layers: Optional[int] = None
+
+    @property
+    def half_length(self) -> int:  # ref:stonkgs_model.py:52
+        return self.max_position_embeddings // 2
+
+    @property
+    def n_backbone_layers(self) -> int:
+        return self.num_hidden_layers if self.backbone_layers is None else self.backbone_layers
+
+
+SPECIAL_IDS = (102, 103, 100)  # [SEP], [MASK], [UNK] of BioBERT's vocab (ref:stonkgs_model.py:116-118)
+
+
+# --------------------------------------------------------------------------------------------- index space
+def kg_row_of_entity_id(e: int) -> Optional[int]:
+    """Quirk Q1: model index -> TSV row.  numeric_indices = [0..K+2] \\ {100,102,103} (ref:stonkgs_model.py:123-129).
+
+    Returns None for the three reserved ids (they map to LM special-token vectors instead)."""
+    if e in SPECIAL_IDS:
+        return None
+    return e - sum(1 for s in SPECIAL_IDS if s < e)
+
+
+def build_kg_table(tsv_rows: Tensor, special_vectors: Dict[int, Tensor]) -> Tensor:
+    """Dense [K+3, H] table indexed by the MODEL's entity id (what ``self.kg_backbone[i]`` returns).
+
+    tsv_rows: [K, H] float64 as read by prepare_df (ref:kg_baseline_model.py:270-280); the reference casts the
+    gathered fp64 rows to CPU fp32 (ref:stonkgs_model.py:193-200), i.e. round-to-nearest, done here once."""
+    K, H = tsv_rows.shape
+    table = torch.empty(K + 3, H, dtype=torch.float32)
+    for e in range(K + 3):
+        r = kg_row_of_entity_id(e)
+        table[e] = special_vectors[e].to(torch.float32) if r is None else tsv_rows[r].to(torch.float32)
+    return table
+
+
+# --------------------------------------------------------------------------------------------- BERT pieces
+def _ln(x: Tensor, sd: Dict[str, Tensor], prefix: str, eps: float) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
+
+
+def _linear(x: Tensor, sd: Dict[str, Tensor], prefix: str) -> Tensor:
+    return F.linear(x, sd[prefix + ".weight"], sd.get(prefix + ".bias"))
+
+
+def bert_embeddings(sd, prefix, cfg, *, input_ids=None, inputs_embeds=None, token_type_ids=None) -> Tensor:
+    """hf BertEmbeddings.forward :98-108 (absolute positions, dropout p=0 / eval)."""
+    if inputs_embeds is None:
+        inputs_embeds = sd[prefix + ".word_embeddings.weight"][input_ids]
+    B, S = inputs_embeds.shape[:2]
+    if token_type_ids is None:
+        token_type_ids = torch.zeros(B, S, dtype=torch.long)
+    pos = sd[prefix + ".position_embeddings.weight"][:S][None]
+    typ = sd[prefix + ".token_type_embeddings.weight"][token_type_ids]
+    return _ln(inputs_embeds + typ + pos, sd, prefix + ".LayerNorm", cfg.layer_norm_eps)
+
+
+def bert_layer(x: Tensor, sd, prefix: str, cfg: OracleConfig, mask_bias: Optional[Tensor]) -> Tensor:
+    B, S, H = x.shape
+    nh = cfg.num_attention_heads
+    d = H // nh
+
+    def heads(t):
+        return t.view(B, S, nh, d).transpose(1, 2)
+
+    q = heads(_linear(x, sd, prefix + ".attention.self.query"))
+    k = heads(_linear(x, sd, prefix + ".attention.self.key"))
+    v = heads(_linear(x, sd, prefix + ".attention.self.value"))
+    scores = q @ k.transpose(-1, -2) / math.sqrt(d)
+    if mask_bias is not None:
+        scores = scores + mask_bias
+    ctx = (torch.softmax(scores, dim=-1) @ v).transpose(1, 2).reshape(B, S, H)
+    h1 = _ln(_linear(ctx, sd, prefix + ".attention.output.dense") + x, sd, prefix + ".attention.output.LayerNorm",
+             cfg.layer_norm_eps)
+    inter = F.gelu(_linear(h1, sd, prefix + ".intermediate.dense"))  # exact erf GELU (hidden_act="gelu")
+    return _ln(_linear(inter, sd, prefix + ".output.dense") + h1, sd, prefix + ".output.LayerNorm", cfg.layer_norm_eps)
+
+
+def bert_encoder(x, sd, prefix, cfg, n_layers, attention_mask=None, collect: Optional[list] = None) -> Tensor:
+    mask_bias = None
+    if attention_mask is not None:  # additive key-padding mask [B,1,1,S]
+        mask_bias = (1.0 - attention_mask[:, None, None, :].to(x.dtype)) * torch.finfo(x.dtype).min
+    for i in range(n_layers):
+        x = bert_layer(x, sd, f"{prefix}.layer.{i}", cfg, mask_bias)
+        if collect is not None:
+            collect.append(x)
+    return x
+
+
+def lm_backbone_forward(sd, cfg: OracleConfig, input_ids: Tensor) -> Tensor:
+    """`self.lm_backbone(ids)[0]`: full BERT forward, NO attention mask (quirk Q5, ref:stonkgs_model.py:178)."""
+    x = bert_embeddings(sd, "lm_backbone.embeddings", cfg, input_ids=input_ids)
+    return bert_encoder(x, sd, "lm_backbone.encoder", cfg, cfg.n_backbone_layers)
+
+
+def special_vectors(sd, cfg: OracleConfig) -> Dict[int, Tensor]:
+    """Quirk Q2: kg_backbone[sid] = lm_backbone([[sid]])[0][0][0] (ref:stonkgs_model.py:138-141)."""
+    return {sid: lm_backbone_forward(sd, cfg, torch.tensor([[sid]]))[0, 0] for sid in SPECIAL_IDS}
+
+
+# --------------------------------------------------------------------------------------------- the hot function
+def forward(sd: Dict[str, Tensor], cfg: OracleConfig, kg_table: Tensor, input_ids: Tensor,
+            attention_mask: Optional[Tensor] = None, token_type_ids: Optional[Tensor] = None,
+            masked_lm_labels: Optional[Tensor] = None, ent_masked_lm_labels: Optional[Tensor] = None,
+            next_sentence_labels: Optional[Tensor] = None, collect_layers: bool = False) -> Dict[str, Tensor]:
+    """ref:src/stonkgs/models/stonkgs_model.py:149-258, step numbers as in SURVEY.md section 3.2."""
+    half = cfg.half_length
+    # 1. frozen LM backbone on the text half
+    token_embeddings = lm_backbone_forward(sd, cfg, input_ids[:, :half])
+    # 2. KG gather (KeyError for ids outside the table, like the reference's dict lookup)
+    ent_ids = input_ids[:, half:]
+    if ent_ids.numel() and (int(ent_ids.min()) < 0 or int(ent_ids.max()) >= kg_table.shape[0]):
+        raise KeyError(int(ent_ids.max()))
+    ent_embeddings = kg_table[ent_ids]
+    # 3. concat, fp32
+    inputs_embeds = torch.cat([token_embeddings, ent_embeddings], dim=1).to(torch.float32)
+    # 4. trainable encoder + pooler
+    emb = bert_embeddings(sd, "bert.embeddings", cfg, inputs_embeds=inputs_embeds, token_type_ids=token_type_ids)
+    layers: Optional[list] = [] if collect_layers else None
+    seq = bert_encoder(emb, sd, "bert.encoder", cfg, cfg.num_hidden_layers, attention_mask, layers)
+    pooled = torch.tanh(_linear(seq[:, 0], sd, "bert.pooler.dense"))
+    # 6. heads
+    t = _ln(F.gelu(_linear(seq, sd, "cls.predictions.transform.dense")), sd, "cls.predictions.transform.LayerNorm",
+            cfg.layer_norm_eps)
+    text_logits = F.linear(t[:, :half], sd["cls.predictions.text_decoder.weight"])
+    ent_logits = F.linear(t[:, half:], sd["cls.predictions.entity_decoder.weight"])
+    nsp_logits = _linear(pooled, sd, "cls.seq_relationship")
+    out = {"inputs_embeds": inputs_embeds, "embedding_output": emb, "hidden_states": seq, "pooler_output": pooled,
+           "transform_output": t, "text_logits": text_logits, "ent_logits": ent_logits, "nsp_logits": nsp_logits}
+    if collect_layers:
+        out["layers"] = layers
+    # 7. loss
+    if masked_lm_labels is not None and ent_masked_lm_labels is not None and next_sentence_labels is not None:
+        lt = F.cross_entropy(text_logits.reshape(-1, cfg.vocab_size), masked_lm_labels.reshape(-1))
+        le = F.cross_entropy(ent_logits.reshape(-1, cfg.kg_vocab_size), ent_masked_lm_labels.reshape(-1))
+        ln = F.cross_entropy(nsp_logits.reshape(-1, 2), next_sentence_labels.reshape(-1))
+        out.update(loss=lt + le + ln, masked_lm_loss=lt, ent_masked_lm_loss=le, next_sentence_loss=ln)
+    return out
+
+
+# --------------------------------------------------------------------------------------------- parameters
+def trainable_names(sd: Dict[str, Tensor]) -> List[str]:
+    """Parameters that receive a gradient in the reference (quirk Q4 removes the dead ones, lm_backbone is frozen)."""
+    dead = ("bert.embeddings.word_embeddings.weight", "cls.predictions.bias", "cls.predictions.decoder.weight",
+            "cls.predictions.decoder.bias", "cls.predictions.text_bias", "cls.predictions.entity_bias",
+            "cls.predictions.decoder.text_bias", "cls.predictions.decoder.entity_bias")
+    return [k for k in sd if not k.startswith("lm_backbone.") and k not in dead]
+
+
+def init_state_dict(cfg: OracleConfig, seed: int = 0, std: float = 0.02, bf16_exact: bool = True) -> Dict[str, Tensor]:
+    """Random-init weights in HF layout (N(0, std) matrices/embeddings, zero biases, unit LayerNorm), optionally
+    rounded to bf16-representable values so a bf16 implementation starts from bit-identical weights."""
+    g = torch.Generator().manual_seed(seed)
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    sd: Dict[str, Tensor] = {}
+
+    def mat(*shape):
+        w = torch.randn(*shape, generator=g) * std
+        return w.to(torch.bfloat16).to(torch.float32) if bf16_exact else w
+
+    def vec(n, noise=0.0, base=0.0):
+        w = base + torch.randn(n, generator=g) * noise
+        return w.to(torch.bfloat16).to(torch.float32) if bf16_exact else w
+
+    def bert(prefix, n_layers, with_pooler=True):
+        sd[prefix + ".embeddings.word_embeddings.weight"] = mat(cfg.vocab_size, H)
+        sd[prefix + ".embeddings.position_embeddings.weight"] = mat(cfg.max_position_embeddings, H)
+        sd[prefix + ".embeddings.token_type_embeddings.weight"] = mat(cfg.type_vocab_size, H)
+        sd[prefix + ".embeddings.LayerNorm.weight"] = vec(H, 0.05, 1.0)
+        sd[prefix + ".embeddings.LayerNorm.bias"] = vec(H, 0.02)
+        for i in range(n_layers):
+            p = f"{prefix}.encoder.layer.{i}"
+            for n in ("query", "key", "value"):
+                sd[f"{p}.attention.self.{n}.weight"] = mat(H, H)
+                sd[f"{p}.attention.self.{n}.bias"] = vec(H, 0.02)
+            sd[f"{p}.attention.output.dense.weight"] = mat(H, H)
+            sd[f"{p}.attention.output.dense.bias"] = vec(H, 0.02)
+            sd[f"{p}.attention.output.LayerNorm.weight"] = vec(H, 0.05, 1.0)
+            sd[f"{p}.attention.output.LayerNorm.bias"] = vec(H, 0.02)
+            sd[f"{p}.intermediate.dense.weight"] = mat(I, H)
+            sd[f"{p}.intermediate.dense.bias"] = vec(I, 0.02)
+            sd[f"{p}.output.dense.weight"] = mat(H, I)
+            sd[f"{p}.output.dense.bias"] = vec(H, 0.02)
+            sd[f"{p}.output.LayerNorm.weight"] = vec(H, 0.05, 1.0)
+            sd[f"{p}.output.LayerNorm.bias"] = vec(H, 0.02)
+        if with_pooler:
+            sd[prefix + ".pooler.dense.weight"] = mat(H, H)
+            sd[prefix + ".pooler.dense.bias"] = vec(H, 0.02)
+
+    bert("bert", cfg.num_hidden_layers)
+    sd["cls.predictions.bias"] = torch.zeros(cfg.vocab_size)
+    sd["cls.predictions.transform.dense.weight"] = mat(H, H)
+    sd["cls.predictions.transform.dense.bias"] = vec(H, 0.02)
+    sd["cls.predictions.transform.LayerNorm.weight"] = vec(H, 0.05, 1.0)
+    sd["cls.predictions.transform.LayerNorm.bias"] = vec(H, 0.02)
+    sd["cls.predictions.text_decoder.weight"] = mat(cfg.vocab_size, H)
+    sd["cls.predictions.entity_decoder.weight"] = mat(cfg.kg_vocab_size, H)
+    sd["cls.predictions.text_bias"] = torch.zeros(cfg.vocab_size)
+    sd["cls.predictions.entity_bias"] = torch.zeros(cfg.kg_vocab_size)
+    sd["cls.seq_relationship.weight"] = mat(2, H)
+    sd["cls.seq_relationship.bias"] = vec(2, 0.02)
+    bert("lm_backbone", cfg.n_backbone_layers)
+    return sd
+
+
+# --------------------------------------------------------------------------------------------- optimizer step
+def linear_schedule_lr(base_lr: float, step: int, max_steps: int, warmup: int = 0) -> float:
+    """hf get_linear_schedule_with_warmup as configured by the reference (0 warm-up): lr used BY optimizer step
+    number `step` (0-based) = base * max(0, (max_steps - step) / max_steps)."""
+    if step < warmup:
+        return base_lr * step / max(1, warmup)
+    return base_lr * max(0.0, (max_steps - step) / max(1, max_steps - warmup))
+
+
+@dataclass
+class AdamState:
+    step: int = 0
+    m: Dict[str, Tensor] = field(default_factory=dict)
+    v: Dict[str, Tensor] = field(default_factory=dict)
+
+
+def train_step(sd: Dict[str, Tensor], cfg: OracleConfig, kg_table: Tensor, batch: Dict[str, Tensor], state: AdamState,
+               base_lr: float = 1e-4, max_steps: int = 200, max_grad_norm: float = 1.0, betas=(0.9, 0.999),
+               eps: float = 1e-8, weight_decay: float = 0.0) -> Dict[str, Tensor]:
+    """One Trainer optimizer step (forward, backward, clip, AdamW, schedule); updates `sd` in place.
+    Returns loss terms, the pre-clip global grad norm and the gradients (for parity checks)."""
+    names = trainable_names(sd)
+    params = {k: sd[k].detach().clone().requires_grad_(True) for k in names}
+    work = dict(sd)
+    work.update(params)
+    out = forward(work, cfg, kg_table, **batch)
+    grads = torch.autograd.grad(out["loss"], [params[k] for k in names], allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(sd[k])) for k, g in zip(names, grads)}
+    total_norm = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    coef = float(min(1.0, max_grad_norm / (float(total_norm) + 1e-6))) if max_grad_norm and max_grad_norm > 0 else 1.0
+    lr = linear_schedule_lr(base_lr, state.step, max_steps)
+    state.step += 1
+    b1, b2 = betas
+    bc1, bc2 = 1 - b1 ** state.step, 1 - b2 ** state.step
+    with torch.no_grad():
+        for k in names:
+            g = grads[k] * coef
+            m = state.m.setdefault(k, torch.zeros_like(sd[k]))
+            v = state.v.setdefault(k, torch.zeros_like(sd[k]))
+            p = sd[k]
+            p.mul_(1 - lr * weight_decay)
+            m.mul_(b1).add_(g, alpha=1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+            p.addcdiv_(m, denom, value=-lr / bc1)
+    res = {k: out[k].detach() for k in ("loss", "masked_lm_loss", "ent_masked_lm_loss", "next_sentence_loss")}
+    res.update(grad_norm=total_norm, lr=lr, grads=grads)
+    return res
+
+
+# --------------------------------------------------------------------------------------------- masking (integer-exact)
+def replace_mlm_tokens(tokens: Sequence[int], vocab_len: int, mask_id: int = 103, masked_tokens_percentage: float = 0.15,
+                       unmasked_label_id: int = -100, rng=random) -> Tuple[List[int], List[int]]:
+    """ref:src/stonkgs/data/indra_for_pretraining.py:33-77; consumes `rng` (Python's Mersenne Twister) in the same
+    call order: one sample() of int(n*0.15) positions, then per position random() [<0.8 -> mask], else random()
+    [<0.5 -> keep] else randint(0, vocab_len-1)."""
+    inp = list(tokens)
+    labels = [unmasked_label_id] * len(inp)
+    positions = rng.sample(range(len(inp)), int(len(inp) * masked_tokens_percentage))
+    for pos in positions:
+        if rng.random() < 0.8:
+            tok = mask_id
+        elif rng.random() < 0.5:
+            tok = tokens[pos]
+        else:
+            tok = rng.randint(0, vocab_len - 1)
+        inp[pos] = tok
+        labels[pos] = tokens[pos]
+    return inp, labels
+
+
+def negative_nsp_index_pairs(n_rows: int, proportion: float = 0.25, rng=random) -> List[Tuple[int, int]]:
+    """ref:indra_for_pretraining.py:80-126: (text row i, entity row j) pairs of the appended negatives."""
+    k = int(n_rows * proportion)
+    a = rng.sample(range(n_rows), k)
+    b = rng.sample(range(n_rows), k)
+    return list(zip(a, b))

@@ -24,14 +24,15 @@ EPI_GELU_BWD = 1 << 6
 EPI_DROPOUT = 1 << 7
 EPI_DEBUG_REGSTAGE = 1 << 16
 LN_DROPOUT = 1 << 0
+SMALL_TANH = 1
+SMALL_X_F32 = 16
 
 _vp, _i32, _i64, _f32, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 
 # name -> argtypes; every launcher returns int (0 ok, <0 bad argument, >0 hipError_t)
 _SIGNATURES = {
-    "stonk_abi_version": [],
     "stonk_gemm_nt_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i64,
-                           _f32, _i32, _vp, _f32, _u32, _vp],
+                           _f32, _i32, _vp, _vp, _f32, _u32, _vp],
     "stonk_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _f32, _u32, _vp],
     "stonk_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _u32, _f32, _u32,
                             _vp],
@@ -46,13 +47,14 @@ _SIGNATURES = {
     "stonk_transpose_bf16": [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp],
     "stonk_transpose_f32_to_bf16": [_vp, _vp, _i64, _i32, _i64, _vp],
     "stonk_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
-    "stonk_label_compact": [_vp, _i64, _vp, _vp, _vp, _vp],
-    "stonk_gather_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i64, _vp],
-    "stonk_scatter_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i64, _vp],
-    "stonk_softmax_xent_fwd_bwd": [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _f32, _vp, _vp],
+    "stonk_label_compact": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "stonk_gather_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _vp],
+    "stonk_scatter_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp],
+    "stonk_softmax_xent_fwd_bwd": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _f32, _vp, _vp],
+    "stonk_nsp_xent_fwd_bwd": [_vp, _vp, _i32, _i32, _vp, _vp, _f32, _vp, _vp],
+    "stonk_loss_finalize": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "stonk_small_linear_fwd": [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
-    "stonk_small_linear_bwd": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
-    "stonk_nsp_xent_fwd_bwd": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _f32, _vp, _vp],
+    "stonk_small_linear_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "stonk_sumsq_f32": [_vp, _i64, _vp, _vp],
     "stonk_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _f32, _f32,
                          _vp],
@@ -87,12 +89,14 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = C.c_int
+        handle.stonk_abi_version.argtypes = []
+        handle.stonk_abi_version.restype = C.c_int
         _lib = handle
     return _lib
 
 
 def exported_symbols():
-    return sorted(_SIGNATURES)
+    return sorted(list(_SIGNATURES) + ["stonk_abi_version"])
 
 
 def check(status: int, name: str) -> None:

@@ -1,0 +1,523 @@
+// Fused scaled-dot-product attention for the STonKGs encoder (head_dim 64, bf16 MFMA, fp32 softmax):
+// forward (flash-style online softmax, never materialises the S x S scores) and backward (dQ kernel +
+// dK/dV kernel, both recomputing P from the forward's log-sum-exp; no atomics, bitwise reproducible).
+//
+// Replaces hf:models/bert/modeling_bert.py BertSelfAttention :164-203 (eager path :111-136):
+//   softmax(Q K^T / sqrt(d) + (1 - attention_mask) * -inf) -> dropout -> . V
+// The key-padding mask is read straight from the int64 attention_mask [B,S] (0 = masked); the frozen LM
+// backbone passes no mask (quirk Q5: ref:src/stonkgs/models/stonkgs_model.py:178).
+//
+// Layout: q/k/v are column slices of one [T, 3H] projection output (row stride `ld`), head h at columns
+// h*64..h*64+63 - no head-major permute is ever written. MFMA orientation follows the CDNA4 playbook:
+//  * forward and dQ compute S^T = K.Q^T (key index in the accumulator registers, query on the lane), so
+//    softmax statistics are per-lane scalars and P^T feeds the next MFMA as B operand with no LDS trip;
+//  * dK/dV compute S = Q.K^T (key on the lane) so P and dS feed dV^T / dK^T the same way.
+// K^T / V^T / Q^T / dO^T operands come from row-major LDS tiles through ds_read_b64_tr_b16.
+#include "common.h"
+#include "stonk_flags.h"
+
+namespace {
+
+constexpr int HD = 64;        // head dim
+constexpr int TK = 64;        // rows per LDS tile
+constexpr int ROWB = 128;     // bytes per tile row
+constexpr int TILEB = TK * ROWB;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float NEG_BIG = -1.0e30f;
+
+struct AttnArgs {
+  const bf16* q;
+  const bf16* k;
+  const bf16* v;
+  long ld;            // row stride (elements) of q/k/v
+  const long* mask;   // [B,S] or null
+  bf16* out;          // fwd: context [T, ldo]
+  long ldo;
+  float* lse;         // [B, NH, S] natural-log LSE of the scaled+masked scores
+  // backward only
+  const bf16* dout;   // [T, lddo]
+  long lddo;
+  const float* delta; // [B, NH, S]
+  bf16* dq;
+  bf16* dk;
+  bf16* dv;
+  long ldd;           // row stride of dq/dk/dv
+  int B, NH, S;
+  float scale;
+  uint32_t drop_thr24;
+  float drop_scale;
+  uint32_t seed;
+};
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+// byte offset of element (row, col) inside a [64][64] bf16 tile image
+__device__ __forceinline__ int tile_off(int row, int col) {
+  return row * ROWB + ((((col >> 3) ^ swz(row)) << 4) | ((col & 7) << 1));
+}
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// A/B fragment of a 32x32x16 MFMA read by rows: lane (r, hh) gets tile[row0 + r][16*st + 8*hh .. +7]
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int row0, int st, int r, int hh) {
+  return *(const bf16x8*)(tile + tile_off(row0 + r, 16 * st + 8 * hh));
+}
+
+// Transposed A fragment: lane (r = column c0 + (lane & 31), hh) gets tile[row0 + 8*(j>>2) + 4*hh + (j&3)][col]
+// for j = 0..7: exactly the k order of an accumulator tile reused as B operand (guide section 3).
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int c0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int col = c0 + 16 * (g & 1) + 4 * (i & 3);
+  const int row = row0 + 4 * (g >> 1) + (i >> 2);
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + tile_off(row, col)));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + tile_off(row + 8, col)));
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// stage a [64][64] bf16 tile: 512 16-byte chunks over 256 threads
+struct Stage2 {
+  bf16x8 c[2];
+};
+__device__ __forceinline__ void stage_load(Stage2& s, const bf16* base, long ld, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 256 * i;
+    s.c[i] = *(const bf16x8*)(base + (long)(id >> 3) * ld + (id & 7) * 8);
+  }
+}
+__device__ __forceinline__ void stage_store(const Stage2& s, char* tile, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 256 * i;
+    *(bf16x8*)(tile + tile_off(id >> 3, (id & 7) * 8)) = s.c[i];
+  }
+}
+
+__device__ __forceinline__ float keep_fac(uint32_t idx, const AttnArgs& p) {
+  return stonk_keep(idx, p.seed, p.drop_thr24) ? p.drop_scale : 0.f;
+}
+
+// ------------------------------------------------------------------ forward
+template <bool HAS_MASK, bool DROPOUT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * TILEB + TK * 4];
+  char* Ks = lds;
+  char* Vs = lds + TILEB;
+  float* Mb = (float*)(lds + 2 * TILEB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int S = p.S;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const long tok0 = (long)b * S;
+  const float sc2 = p.scale * LOG2E;
+
+  bf16x8 qf[4];
+  {
+    const bf16* qrow = p.q + (tok0 + q0 + r) * p.ld + h * HD;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8*)(qrow + 16 * st + 8 * hh);
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) o[0][i] = o[1][i] = 0.f;
+  float m = NEG_BIG, l = 0.f;
+
+  const bf16* kbase = p.k + tok0 * p.ld + h * HD;
+  const bf16* vbase = p.v + tok0 * p.ld + h * HD;
+  const int ntiles = S / TK;
+  Stage2 sk, sv;
+  stage_load(sk, kbase, p.ld, tid);
+  stage_load(sv, vbase, p.ld, tid);
+  const uint32_t drop_row = (uint32_t)(((long)(b * p.NH + h) * S + q0 + r) * S);
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    stage_store(sk, Ks, tid);
+    stage_store(sv, Vs, tid);
+    if (HAS_MASK && tid < TK) Mb[tid] = p.mask[tok0 + kt * TK + tid] != 0 ? 0.f : NEG_BIG;
+    __syncthreads();
+    if (kt + 1 < ntiles) {
+      stage_load(sk, kbase + (long)(kt + 1) * TK * p.ld, p.ld, tid);
+      stage_load(sv, vbase + (long)(kt + 1) * TK * p.ld, p.ld, tid);
+    }
+    // S^T = K . Q^T for the two 32-key halves of the tile
+    f32x16 s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[sub][i] = 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) s[sub] = mfma32(row_frag(Ks, sub * 32, st, r, hh), qf[st], s[sub]);
+    }
+    float tmax = NEG_BIG;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 mb = {0.f, 0.f, 0.f, 0.f};
+        if (HAS_MASK) mb = *(const f32x4*)(Mb + sub * 32 + 8 * g + 4 * hh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float t = s[sub][4 * g + j] * sc2 + mb[j];
+          s[sub][4 * g + j] = t;
+          tmax = fmaxf(tmax, t);
+        }
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    m = m_new;
+    float rs = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float e = __builtin_amdgcn_exp2f(s[sub][i] - m);
+        s[sub][i] = e;
+        rs += e;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l = l * alpha + rs;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      o[0][i] *= alpha;
+      o[1][i] *= alpha;
+    }
+    // O^T += V^T . P^T
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float e = s[sub][8 * ks + j];
+          if (DROPOUT) {
+            const int key = kt * TK + sub * 32 + 16 * ks + 8 * (j >> 2) + 4 * hh + (j & 3);
+            e *= keep_fac(drop_row + key, p);
+          }
+          pf[j] = (bf16)e;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(tr_frag(Vs, sub * 32 + 16 * ks, dt * 32, lane), pf, o[dt]);
+      }
+    __syncthreads();
+  }
+  const float inv = 1.f / l;
+  bf16* orow = p.out + (tok0 + q0 + r) * p.ldo + h * HD;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 v = {(bf16)(o[dt][4 * g] * inv), (bf16)(o[dt][4 * g + 1] * inv), (bf16)(o[dt][4 * g + 2] * inv),
+                  (bf16)(o[dt][4 * g + 3] * inv)};
+      *(bf16x4*)(orow + dt * 32 + 8 * g + 4 * hh) = v;
+    }
+  if (hh == 0 && p.lse) p.lse[(long)(b * p.NH + h) * S + q0 + r] = (m + __builtin_amdgcn_logf(l)) * LN2;
+}
+
+// ------------------------------------------------------------------ delta = rowsum(dO * O) per (b, h, q)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, long ldo,
+                                                         const bf16* __restrict__ dout, long lddo,
+                                                         float* __restrict__ delta, int B, int NH, int S) {
+  // one 8-lane group per (token, head): 8 x 16-byte chunks = 64 columns
+  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  const long total = (long)B * S * NH;
+  float acc = 0.f;
+  if (gid < total) {
+    const long tok = gid / NH;
+    const int h = (int)(gid - tok * NH);
+    const bf16x8 a = *(const bf16x8*)(o + tok * ldo + h * HD + sub * 8);
+    const bf16x8 d = *(const bf16x8*)(dout + tok * lddo + h * HD + sub * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)d[j];
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  if (gid < total && sub == 0) {
+    const long tok = gid / NH;
+    const int h = (int)(gid - tok * NH);
+    const long b = tok / S;
+    const int s = (int)(tok - b * S);
+    delta[((long)b * NH + h) * S + s] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ backward: dQ (query on the lane)
+template <bool HAS_MASK, bool DROPOUT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * TILEB + TK * 4];
+  char* Ks = lds;
+  char* Vs = lds + TILEB;
+  float* Mb = (float*)(lds + 2 * TILEB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int S = p.S;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const long tok0 = (long)b * S;
+  const float sc2 = p.scale * LOG2E;
+
+  bf16x8 qf[4], dof[4];
+  {
+    const bf16* qrow = p.q + (tok0 + q0 + r) * p.ld + h * HD;
+    const bf16* drow = p.dout + (tok0 + q0 + r) * p.lddo + h * HD;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      qf[st] = *(const bf16x8*)(qrow + 16 * st + 8 * hh);
+      dof[st] = *(const bf16x8*)(drow + 16 * st + 8 * hh);
+    }
+  }
+  const long stat = (long)(b * p.NH + h) * S + q0 + r;
+  const float lse2 = p.lse[stat] * LOG2E;
+  const float dlt = p.delta[stat];
+  f32x16 dq[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dq[0][i] = dq[1][i] = 0.f;
+
+  const bf16* kbase = p.k + tok0 * p.ld + h * HD;
+  const bf16* vbase = p.v + tok0 * p.ld + h * HD;
+  const int ntiles = S / TK;
+  Stage2 sk, sv;
+  stage_load(sk, kbase, p.ld, tid);
+  stage_load(sv, vbase, p.ld, tid);
+  const uint32_t drop_row = (uint32_t)(((long)(b * p.NH + h) * S + q0 + r) * S);
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    stage_store(sk, Ks, tid);
+    stage_store(sv, Vs, tid);
+    if (HAS_MASK && tid < TK) Mb[tid] = p.mask[tok0 + kt * TK + tid] != 0 ? 0.f : NEG_BIG;
+    __syncthreads();
+    if (kt + 1 < ntiles) {
+      stage_load(sk, kbase + (long)(kt + 1) * TK * p.ld, p.ld, tid);
+      stage_load(sv, vbase + (long)(kt + 1) * TK * p.ld, p.ld, tid);
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        s = mfma32(row_frag(Ks, sub * 32, st, r, hh), qf[st], s);      // S^T[k][q]
+        dp = mfma32(row_frag(Vs, sub * 32, st, r, hh), dof[st], dp);   // dP^T[k][q] = sum_d V[k][d] dO[q][d]
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 mb = {0.f, 0.f, 0.f, 0.f};
+        if (HAS_MASK) mb = *(const f32x4*)(Mb + sub * 32 + 8 * g + 4 * hh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = 4 * g + j;
+          const float pr = __builtin_amdgcn_exp2f(s[i] * sc2 + mb[j] - lse2);
+          float dpv = dp[i];
+          if (DROPOUT) dpv *= keep_fac(drop_row + kt * TK + sub * 32 + 8 * g + 4 * hh + j, p);
+          s[i] = pr * (dpv - dlt);  // dS^T
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 dsf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsf[j] = (bf16)s[8 * ks + j];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tr_frag(Ks, sub * 32 + 16 * ks, dt * 32, lane), dsf, dq[dt]);
+      }
+    }
+    __syncthreads();
+  }
+  bf16* orow = p.dq + (tok0 + q0 + r) * p.ldd + h * HD;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 v = {(bf16)(dq[dt][4 * g] * p.scale), (bf16)(dq[dt][4 * g + 1] * p.scale),
+                  (bf16)(dq[dt][4 * g + 2] * p.scale), (bf16)(dq[dt][4 * g + 3] * p.scale)};
+      *(bf16x4*)(orow + dt * 32 + 8 * g + 4 * hh) = v;
+    }
+}
+
+// ------------------------------------------------------------------ backward: dK, dV (key on the lane)
+template <bool HAS_MASK, bool DROPOUT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * TILEB + 2 * TK * 4];
+  char* Qs = lds;
+  char* Ds = lds + TILEB;
+  float* Ls = (float*)(lds + 2 * TILEB);  // lse * log2(e) per query row of the tile
+  float* Dl = Ls + TK;                    // delta per query row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int S = p.S;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const long tok0 = (long)b * S;
+  const float sc2 = p.scale * LOG2E;
+
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16* krow = p.k + (tok0 + k0 + r) * p.ld + h * HD;
+    const bf16* vrow = p.v + (tok0 + k0 + r) * p.ld + h * HD;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      kf[st] = *(const bf16x8*)(krow + 16 * st + 8 * hh);
+      vf[st] = *(const bf16x8*)(vrow + 16 * st + 8 * hh);
+    }
+  }
+  float mb = 0.f;
+  if (HAS_MASK) mb = p.mask[tok0 + k0 + r] != 0 ? 0.f : NEG_BIG;
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;
+
+  const bf16* qbase = p.q + tok0 * p.ld + h * HD;
+  const bf16* dbase = p.dout + tok0 * p.lddo + h * HD;
+  const long statbase = (long)(b * p.NH + h) * S;
+  const int ntiles = S / TK;
+  Stage2 sq, sd;
+  stage_load(sq, qbase, p.ld, tid);
+  stage_load(sd, dbase, p.lddo, tid);
+
+  for (int qt = 0; qt < ntiles; ++qt) {
+    stage_store(sq, Qs, tid);
+    stage_store(sd, Ds, tid);
+    if (tid < TK) Ls[tid] = p.lse[statbase + qt * TK + tid] * LOG2E;
+    else if (tid < 2 * TK) Dl[tid - TK] = p.delta[statbase + qt * TK + tid - TK];
+    __syncthreads();
+    if (qt + 1 < ntiles) {
+      stage_load(sq, qbase + (long)(qt + 1) * TK * p.ld, p.ld, tid);
+      stage_load(sd, dbase + (long)(qt + 1) * TK * p.lddo, p.lddo, tid);
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        s = mfma32(row_frag(Qs, sub * 32, st, r, hh), kf[st], s);    // S[q][k]
+        dp = mfma32(row_frag(Ds, sub * 32, st, r, hh), vf[st], dp);  // dP[q][k] = sum_d dO[q][d] V[k][d]
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 ls = *(const f32x4*)(Ls + sub * 32 + 8 * g + 4 * hh);
+        const f32x4 dl = *(const f32x4*)(Dl + sub * 32 + 8 * g + 4 * hh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = 4 * g + j;
+          const float pr = __builtin_amdgcn_exp2f(s[i] * sc2 + mb - ls[j]);
+          float fac = 1.f;
+          if (DROPOUT) {
+            const int qrow = qt * TK + sub * 32 + 8 * g + 4 * hh + j;
+            fac = keep_fac((uint32_t)((statbase + qrow) * S + k0 + r), p);
+          }
+          s[i] = pr * fac;                        // dropped P (feeds dV)
+          dp[i] = pr * (dp[i] * fac - dl[j]);     // dS (feeds dK)
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 pf, dsf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pf[j] = (bf16)s[8 * ks + j];
+          dsf[j] = (bf16)dp[8 * ks + j];
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = mfma32(tr_frag(Ds, sub * 32 + 16 * ks, dt * 32, lane), pf, dv[dt]);   // dV^T += dO^T . P
+          dk[dt] = mfma32(tr_frag(Qs, sub * 32 + 16 * ks, dt * 32, lane), dsf, dk[dt]);  // dK^T += Q^T . dS
+        }
+      }
+    }
+    __syncthreads();
+  }
+  bf16* krow = p.dk + (tok0 + k0 + r) * p.ldd + h * HD;
+  bf16* vrow = p.dv + (tok0 + k0 + r) * p.ldd + h * HD;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 a = {(bf16)(dk[dt][4 * g] * p.scale), (bf16)(dk[dt][4 * g + 1] * p.scale),
+                  (bf16)(dk[dt][4 * g + 2] * p.scale), (bf16)(dk[dt][4 * g + 3] * p.scale)};
+      bf16x4 c = {(bf16)dv[dt][4 * g], (bf16)dv[dt][4 * g + 1], (bf16)dv[dt][4 * g + 2], (bf16)dv[dt][4 * g + 3]};
+      *(bf16x4*)(krow + dt * 32 + 8 * g + 4 * hh) = a;
+      *(bf16x4*)(vrow + dt * 32 + 8 * g + 4 * hh) = c;
+    }
+}
+
+int check_common(const void* q, const void* k, const void* v, int64_t ld, int B, int NH, int S, int D) {
+  STONK_CHECK_ARG(q && k && v, STONK_EINVAL);
+  STONK_CHECK_ARG(D == HD, STONK_ESHAPE);
+  STONK_CHECK_ARG(B >= 0 && NH > 0 && S > 0 && S % 128 == 0, STONK_ESHAPE);
+  STONK_CHECK_ARG(ld % 8 == 0, STONK_EALIGN);
+  STONK_CHECK_ARG((uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0, STONK_EALIGN);
+  STONK_CHECK_ARG((long)B * NH * S * S < (1L << 32), STONK_ESHAPE);  // 32-bit dropout counter
+  return STONK_OK;
+}
+
+}  // namespace
+
+extern "C" int stonk_attention_fwd(const void* q, const void* k, const void* v, int64_t ld,
+                                   const int64_t* attention_mask, void* out, int64_t ldo, float* lse, int B, int NH,
+                                   int S, int D, float scale, float drop_p, uint32_t seed, void* stream) {
+  int rc = check_common(q, k, v, ld, B, NH, S, D);
+  if (rc) return rc;
+  STONK_CHECK_ARG(out && ldo % 4 == 0, STONK_EINVAL);
+  STONK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, STONK_EINVAL);
+  if (B == 0) return STONK_OK;
+  AttnArgs a = {};
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
+  a.mask = (const long*)attention_mask; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse;
+  a.B = B; a.NH = NH; a.S = S; a.scale = scale;
+  a.drop_thr24 = stonk_drop_thr24(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed;
+  const dim3 grid(S / 128, NH, B), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const bool hm = attention_mask != nullptr, dr = drop_p > 0.f;
+  if (hm && dr) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, block, 0, st, a);
+  else if (hm) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, block, 0, st, a);
+  else if (dr) hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, block, 0, st, a);
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_attention_bwd(const void* q, const void* k, const void* v, int64_t ld,
+                                   const int64_t* attention_mask, const void* out, int64_t ldo, const void* dout,
+                                   int64_t lddo, const float* lse, float* delta_ws, void* dq, void* dk, int64_t ldd,
+                                   void* dv, int B, int NH, int S, int D, float scale, float drop_p, uint32_t seed,
+                                   void* stream) {
+  int rc = check_common(q, k, v, ld, B, NH, S, D);
+  if (rc) return rc;
+  STONK_CHECK_ARG(out && dout && lse && delta_ws && dq && dk && dv, STONK_EINVAL);
+  STONK_CHECK_ARG(ldo % 8 == 0 && lddo % 8 == 0 && ldd % 4 == 0, STONK_EALIGN);
+  STONK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, STONK_EINVAL);
+  if (B == 0) return STONK_OK;
+  AttnArgs a = {};
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
+  a.mask = (const long*)attention_mask; a.lse = (float*)lse;
+  a.dout = (const bf16*)dout; a.lddo = lddo; a.delta = delta_ws;
+  a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ldd = ldd;
+  a.B = B; a.NH = NH; a.S = S; a.scale = scale;
+  a.drop_thr24 = stonk_drop_thr24(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed;
+  hipStream_t st = (hipStream_t)stream;
+  const long groups = (long)B * S * NH;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, st,
+                     (const bf16*)out, (long)ldo, (const bf16*)dout, (long)lddo, delta_ws, B, NH, S);
+  const dim3 grid(S / 128, NH, B), block(256);
+  const bool hm = attention_mask != nullptr, dr = drop_p > 0.f;
+#define LAUNCH_BWD(HM, DR)                                                                  \
+  do {                                                                                      \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HM, DR>), grid, block, 0, st, a);                \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HM, DR>), grid, block, 0, st, a);               \
+  } while (0)
+  if (hm && dr) LAUNCH_BWD(true, true);
+  else if (hm) LAUNCH_BWD(true, false);
+  else if (dr) LAUNCH_BWD(false, true);
+  else LAUNCH_BWD(false, false);
+#undef LAUNCH_BWD
+  return stonk_launch_status();
+}

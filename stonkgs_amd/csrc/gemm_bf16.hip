@@ -31,6 +31,7 @@ struct GemmArgs {
   const bf16* resid;
   bf16* aux;
   const int* m_dev;
+  const int* k_dev;
   long lda, ldb, ldc, ldr, ldaux;
   int M, N, K;
   int flags;
@@ -63,7 +64,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
     M = md < M ? md : M;
   }
   const int ntm = (M + BM - 1) / BM, ntn = p.N / BN;
-  const int nk = (p.K / BK) / p.split_k;
+  // contraction length may also live in device memory (label-sparse wgrad): tiles past it are skipped
+  int nk_total = p.K / BK;
+  if (p.k_dev) {
+    const int kd = (*p.k_dev + BK - 1) / BK;
+    nk_total = kd < nk_total ? kd : nk_total;
+  }
+  const int nk_per = (nk_total + p.split_k - 1) / p.split_k;
   const int per_split = ntm * ntn;
   const int total = per_split * p.split_k;
   const bool one_shot = ((int)gridDim.x == total);
@@ -86,7 +93,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
       rt = tt - ct * ntm;
     }
     const int m0 = rt * BM, n0 = ct * BN;
-    const long k_begin = (long)ks * nk * BK;
+    const long k_begin = (long)ks * nk_per * BK;
+    int nk = nk_total - ks * nk_per;
+    nk = nk < nk_per ? nk : nk_per;
+    if (nk <= 0) continue;  // uniform per block
 
     // ---- staging addresses: each wave moves 32 rows of A and 32 rows of B per K tile (4 + 4 DMA ops)
     const bf16* ga[4];
@@ -261,11 +271,11 @@ int launch(const GemmArgs& a, int grid, hipStream_t st) {
 extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                   int M, int N, int K, int flags, const float* bias, const void* resid,
                                   int64_t ldr, void* aux, int64_t ldaux, float alpha, int split_k,
-                                  const int* m_dev, float drop_p, uint32_t seed, void* stream) {
+                                  const int* m_dev, const int* k_dev, float drop_p, uint32_t seed, void* stream) {
   STONK_CHECK_ARG(A && B && C, STONK_EINVAL);
   STONK_CHECK_ARG(M >= 0 && N > 0 && K > 0, STONK_ESHAPE);
   STONK_CHECK_ARG(N % BN == 0 && K % BK == 0, STONK_ESHAPE);
-  STONK_CHECK_ARG(split_k >= 1 && (K / BK) % split_k == 0, STONK_ESHAPE);
+  STONK_CHECK_ARG(split_k >= 1 && split_k <= K / BK, STONK_ESHAPE);
   STONK_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, STONK_EALIGN);
   STONK_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), STONK_EALIGN);
   const int out_mode = flags & STONK_EPI_OUT_MASK;
@@ -279,7 +289,7 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
 
   GemmArgs a;
   a.A = (const bf16*)A; a.B = (const bf16*)B; a.C = C;
-  a.bias = bias; a.resid = (const bf16*)resid; a.aux = (bf16*)aux; a.m_dev = m_dev;
+  a.bias = bias; a.resid = (const bf16*)resid; a.aux = (bf16*)aux; a.m_dev = m_dev; a.k_dev = k_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldaux = ldaux;
   a.M = M; a.N = N; a.K = K; a.flags = flags; a.alpha = alpha; a.split_k = split_k;
   a.drop_thr24 = stonk_drop_thr24(drop_p);

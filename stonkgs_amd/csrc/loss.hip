@@ -1,0 +1,274 @@
+// Loss-side kernels of the STonKGs step (K11-K14 in SURVEY.md section 2.3): label compaction, row
+// gather/scatter, fused softmax + cross-entropy (forward value AND logits gradient in one sweep), NSP
+// cross-entropy, loss finalisation.
+//
+// Reference semantics: three nn.CrossEntropyLoss() (mean over targets != -100) summed,
+// ref:src/stonkgs/models/stonkgs_model.py:223-245. Only rows whose label is not -100 contribute to the
+// loss or to any gradient, so the decoders run on the compacted labelled rows (identical loss and
+// gradients, SURVEY.md section 8d "label-sparse"); the row count lives in device memory - no host sync.
+#include "common.h"
+#include "stonk_flags.h"
+
+namespace {
+
+// Stable compaction of labels != -100 (single block scan; n = B * half is a few 10^4 at most).
+// rows_out[i] = token row (b*S + offset + pos) of the i-th labelled position, targets_out[i] = its label.
+__global__ __launch_bounds__(1024) void label_compact_kernel(const long* __restrict__ labels, long n, int half, int S,
+                                                             int offset, int* __restrict__ rows_out,
+                                                             int* __restrict__ targets_out, int* __restrict__ count_out) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t == 0) base = 0;
+  __syncthreads();
+  for (long start = 0; start < n; start += 1024) {
+    const long i = start + t;
+    const long lab = i < n ? labels[i] : -100;
+    const int flag = lab != -100;
+    const unsigned long long bal = __ballot(flag);
+    const int prefix = __popcll(bal & ((1ULL << lane) - 1ULL));
+    if (lane == 0) wsum[w] = __popcll(bal);
+    __syncthreads();
+    int woff = 0;
+    for (int j = 0; j < w; ++j) woff += wsum[j];
+    const int b0 = base;
+    if (flag) {
+      const int dst = b0 + woff + prefix;
+      const long b = i / half;
+      rows_out[dst] = (int)(b * S + offset + (i - b * half));
+      targets_out[dst] = (int)lab;
+    }
+    __syncthreads();
+    if (t == 0) {
+      int tot = 0;
+      for (int j = 0; j < 16; ++j) tot += wsum[j];
+      base = b0 + tot;
+    }
+    __syncthreads();
+  }
+  if (t == 0) *count_out = base;
+}
+
+// dst[i] = src[rows[i]] for i < count; rows in [count, roundup(count,128)) are zero-filled so that a
+// 128-row GEMM tile past the count reads zeros.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16* __restrict__ src, long ld_src,
+                                                          const int* __restrict__ rows, const int* __restrict__ count,
+                                                          bf16* __restrict__ dst, long ld_dst, int cols, long cap) {
+  const int cnt = *count;
+  long lim = ((long)(cnt + 127) / 128) * 128;
+  lim = lim < cap ? lim : cap;
+  const int nch = cols >> 3;
+  const long total = lim * nch;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / nch;
+    const int c = (int)(i - r * nch);
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
+    if (r < cnt) v = *(const bf16x8*)(src + (long)rows[r] * ld_src + c * 8);
+    *(bf16x8*)(dst + r * ld_dst + c * 8) = v;
+  }
+}
+
+// dst[rows[i]] = src[i] for i < count (dst rows not named keep their content; the caller zeroes dst first)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16* __restrict__ src, long ld_src,
+                                                           const int* __restrict__ rows, const int* __restrict__ count,
+                                                           bf16* __restrict__ dst, long ld_dst, int cols) {
+  const int cnt = *count;
+  const int nch = cols >> 3;
+  const long total = (long)cnt * nch;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / nch;
+    const int c = (int)(i - r * nch);
+    *(bf16x8*)(dst + (long)rows[r] * ld_dst + c * 8) = *(const bf16x8*)(src + r * ld_src + c * 8);
+  }
+}
+
+// One block per labelled row: online (max, sum-exp) sweep of the fp32 logits, then a second sweep writes
+// dlogits = (softmax - onehot) * gscale / count as bf16 (columns [ncols, npad) = 0). loss_sum += lse - x[target].
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits, long ld, int ncols, int npad,
+                                                           const int* __restrict__ targets, const int* __restrict__ count,
+                                                           float* __restrict__ loss_sum, bf16* __restrict__ dlogits,
+                                                           long ld_d, float gscale, int* __restrict__ err) {
+  __shared__ float red_m[4], red_s[4];
+  const int cnt = *count;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const float g = gscale / (float)cnt;
+  for (int row = blockIdx.x; row < cnt; row += gridDim.x) {
+    const float* x = logits + (long)row * ld;
+    float m = -3.0e38f, s = 0.f;
+    const int n4 = ncols >> 2;
+    for (int i = t; i < n4; i += 256) {
+      const f32x4 v = *(const f32x4*)(x + 4 * i);
+      const float vm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+      if (vm > m) {
+        s *= __expf(m - vm);
+        m = vm;
+      }
+      s += __expf(v[0] - m) + __expf(v[1] - m) + __expf(v[2] - m) + __expf(v[3] - m);
+    }
+    for (int i = (n4 << 2) + t; i < ncols; i += 256) {
+      const float v = x[i];
+      if (v > m) {
+        s *= __expf(m - v);
+        m = v;
+      }
+      s += __expf(v - m);
+    }
+    // combine (m, s) pairs across the wave, then across the 4 waves
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+      const float mn = fmaxf(m, m2);
+      s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+      m = mn;
+    }
+    if (lane == 0) {
+      red_m[w] = m;
+      red_s[w] = s;
+    }
+    __syncthreads();
+    float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+    float Ssum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Ssum += red_s[j] * __expf(red_m[j] - M);
+    const float lse = M + __logf(Ssum);
+    int tgt = targets[row];
+    if (tgt < 0 || tgt >= ncols) {  // torch raises "Target out of bounds"
+      if (t == 0) atomicOr(err, 8);
+      tgt = 0;
+    }
+    if (t == 0) atomicAdd(loss_sum, lse - x[tgt]);
+    if (dlogits) {
+      bf16* d = dlogits + (long)row * ld_d;
+      const int p8 = npad >> 3;
+      for (int i = t; i < p8; i += 256) {
+        const int c0 = i * 8;
+        bf16x8 o;
+        if (c0 + 8 <= ncols) {
+          const f32x4 a = *(const f32x4*)(x + c0), b = *(const f32x4*)(x + c0 + 4);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float v = j < 4 ? a[j] : b[j - 4];
+            float pr = __expf(v - lse);
+            if (c0 + j == tgt) pr -= 1.f;
+            o[j] = (bf16)(pr * g);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float pr = 0.f;
+            if (c0 + j < ncols) {
+              pr = __expf(x[c0 + j] - lse);
+              if (c0 + j == tgt) pr -= 1.f;
+            }
+            o[j] = (bf16)(pr * g);
+          }
+        }
+        *(bf16x8*)(d + c0) = o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// NSP head loss: B rows, C (= 2) classes, fp32. dlogits = (softmax - onehot) * gscale / B.
+__global__ __launch_bounds__(256) void nsp_xent_kernel(const float* __restrict__ logits, const long* __restrict__ labels,
+                                                       int B, int C, float* __restrict__ loss_sum,
+                                                       float* __restrict__ dlogits, float gscale, int* __restrict__ err) {
+  float local = 0.f;
+  int cnt = 0;
+  // count of non-ignored labels (CrossEntropyLoss ignore_index = -100 applies here too)
+  for (int i = 0; i < B; ++i) cnt += labels[i] != -100;
+  for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+    const float* x = logits + (long)b * C;
+    long tgt = labels[b];
+    float m = x[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += __expf(x[c] - m);
+    const float lse = m + __logf(s);
+    const bool ignored = tgt == -100;
+    if (!ignored && (tgt < 0 || tgt >= C)) {
+      atomicOr(err, 16);
+      tgt = 0;
+    }
+    if (!ignored) local += lse - x[tgt];
+    if (dlogits)
+      for (int c = 0; c < C; ++c)
+        dlogits[(long)b * C + c] = ignored ? 0.f : (__expf(x[c] - lse) - (c == tgt ? 1.f : 0.f)) * gscale / (float)cnt;
+  }
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0 && local != 0.f) atomicAdd(loss_sum, local);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(loss_sum + 1, (float)cnt);  // loss_sum[1] = label count
+}
+
+// loss_out[0] = total, [1] = text MLM, [2] = entity MLM, [3] = NSP (each the mean over its own labels)
+__global__ void loss_finalize_kernel(const float* text_sum, const int* text_cnt, const float* ent_sum, const int* ent_cnt,
+                                     const float* nsp_sum_cnt, float* loss_out) {
+  const float lt = *text_sum / (float)*text_cnt;
+  const float le = *ent_sum / (float)*ent_cnt;
+  const float ln = nsp_sum_cnt[0] / nsp_sum_cnt[1];
+  loss_out[0] = lt + le + ln;
+  loss_out[1] = lt;
+  loss_out[2] = le;
+  loss_out[3] = ln;
+}
+
+}  // namespace
+
+extern "C" int stonk_label_compact(const int64_t* labels, int64_t n, int half, int S, int offset, int* rows_out,
+                                   int* targets_out, int* count_out, void* stream) {
+  STONK_CHECK_ARG(labels && rows_out && targets_out && count_out, STONK_EINVAL);
+  STONK_CHECK_ARG(n >= 0 && half > 0 && S >= half && offset >= 0, STONK_ESHAPE);
+  hipLaunchKernelGGL(label_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const long*)labels, (long)n,
+                     half, S, offset, rows_out, targets_out, count_out);
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_gather_rows_bf16(const void* src, int64_t ld_src, const int* rows, const int* count_dev, void* dst,
+                                      int64_t ld_dst, int cols, int64_t cap, void* stream) {
+  STONK_CHECK_ARG(src && rows && count_dev && dst, STONK_EINVAL);
+  STONK_CHECK_ARG(cols > 0 && cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && cap >= 0, STONK_EALIGN);
+  if (cap == 0) return STONK_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (long)ld_src,
+                     rows, count_dev, (bf16*)dst, (long)ld_dst, cols, (long)cap);
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_scatter_rows_bf16(const void* src, int64_t ld_src, const int* rows, const int* count_dev,
+                                       void* dst, int64_t ld_dst, int cols, void* stream) {
+  STONK_CHECK_ARG(src && rows && count_dev && dst, STONK_EINVAL);
+  STONK_CHECK_ARG(cols > 0 && cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0, STONK_EALIGN);
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (long)ld_src,
+                     rows, count_dev, (bf16*)dst, (long)ld_dst, cols);
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_softmax_xent_fwd_bwd(const float* logits, int64_t ld, int ncols, int npad, const int* targets,
+                                          const int* count_dev, float* loss_sum, void* dlogits, int64_t ld_d,
+                                          float grad_scale, int* err_flag, void* stream) {
+  STONK_CHECK_ARG(logits && targets && count_dev && loss_sum && err_flag, STONK_EINVAL);
+  STONK_CHECK_ARG(ncols > 0 && npad >= ncols && npad % 8 == 0 && ld >= npad && ld % 4 == 0, STONK_ESHAPE);
+  STONK_CHECK_ARG(!dlogits || (ld_d >= npad && ld_d % 8 == 0), STONK_ESHAPE);
+  hipLaunchKernelGGL(softmax_xent_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, ncols, npad,
+                     targets, count_dev, loss_sum, (bf16*)dlogits, (long)ld_d, grad_scale, err_flag);
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_nsp_xent_fwd_bwd(const float* logits, const int64_t* labels, int B, int C, float* loss_sum_cnt,
+                                      float* dlogits, float grad_scale, int* err_flag, void* stream) {
+  STONK_CHECK_ARG(logits && labels && loss_sum_cnt && err_flag, STONK_EINVAL);
+  STONK_CHECK_ARG(B > 0 && C > 0 && C <= 64, STONK_ESHAPE);
+  hipLaunchKernelGGL(nsp_xent_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits,
+                     (const long*)labels, B, C, loss_sum_cnt, dlogits, grad_scale, err_flag);
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_loss_finalize(const float* text_sum, const int* text_cnt, const float* ent_sum, const int* ent_cnt,
+                                   const float* nsp_sum_cnt, float* loss_out, void* stream) {
+  STONK_CHECK_ARG(text_sum && text_cnt && ent_sum && ent_cnt && nsp_sum_cnt && loss_out, STONK_EINVAL);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, text_sum, text_cnt, ent_sum, ent_cnt,
+                     nsp_sum_cnt, loss_out);
+  return stonk_launch_status();
+}

@@ -1,0 +1,234 @@
+// HBM-bound elementwise / layout kernels of the optimizer step (K16 in SURVEY.md section 2.3):
+// global grad-norm, fused clip + AdamW + bf16 weight refresh + grad zeroing over ONE flat fp32 buffer,
+// and the tiled transposes that feed the NT GEMM (wgrad operands, W^T copies for dgrad).
+//
+// Semantics follow what the reference's driver calls (ref:src/stonkgs/models/stonkgs_pretraining.py:171-223):
+// hf:trainer.py:1780-1796 -> clip_grad_norm_(max_norm=1.0) then torch.optim.AdamW(betas=(0.9,0.999),
+// eps=1e-8, weight_decay=0.0).step(), then model.zero_grad().
+#include "common.h"
+#include "stonk_flags.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+  float acc = 0.f;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = *(const f32x4*)(x + 4 * i);
+    acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0)
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) acc += x[i] * x[i];
+  acc = wave_sum(acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+// One pass over the flat buffers: p, g, m, v read; p, m, v, bf16(p) written; g zeroed.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16* __restrict__ pb, long n, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2,
+                                                    const float* __restrict__ gnorm_sq, float max_norm,
+                                                    float grad_scale) {
+  float coef = grad_scale;
+  if (gnorm_sq && max_norm > 0.f) {
+    // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
+    const float total = sqrtf(*gnorm_sq) * grad_scale;
+    const float c = max_norm / (total + 1e-6f);
+    coef *= c < 1.f ? c : 1.f;
+  }
+  const float step = lr / bc1;
+  const float inv_sqrt_bc2 = rsqrtf(bc2);
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 pp = *(f32x4*)(p + 4 * i), gg = *(f32x4*)(g + 4 * i), mm = *(f32x4*)(m + 4 * i), vv = *(f32x4*)(v + 4 * i);
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = gg[j] * coef;
+      float w = pp[j] * (1.f - lr * wd);
+      mm[j] = b1 * mm[j] + (1.f - b1) * gr;
+      vv[j] = b2 * vv[j] + (1.f - b2) * gr * gr;
+      const float denom = sqrtf(vv[j]) * inv_sqrt_bc2 + eps;
+      w -= step * (mm[j] / denom);
+      pp[j] = w;
+      o[j] = (bf16)w;
+    }
+    *(f32x4*)(p + 4 * i) = pp;
+    *(f32x4*)(m + 4 * i) = mm;
+    *(f32x4*)(v + 4 * i) = vv;
+    *(f32x4*)(g + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pb) *(bf16x4*)(pb + 4 * i) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, float s) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= s;
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, bf16* __restrict__ y, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 v = *(const f32x4*)(x + 4 * i);
+    *(bf16x4*)(y + 4 * i) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+  }
+  if (blockIdx.x == 0)
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) y[i] = (bf16)x[i];
+}
+
+// 64x64 tile transpose through LDS. SrcT = bf16 or float; output bf16. Rows at or past *rows_dev read as zero
+// (label-sparse decoder operands); optional column sums of the source (bias gradients) via atomics.
+constexpr int TT = 64;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+__device__ __forceinline__ unsigned short bf16_bits(float f) {
+  const bf16 b = (bf16)f;
+  unsigned short u;
+  __builtin_memcpy(&u, &b, 2);
+  return u;
+}
+__device__ __forceinline__ float bits_to_float(unsigned short u) {
+  return __uint_as_float(((unsigned)u) << 16);
+}
+template <typename SrcT>
+__global__ __launch_bounds__(256) void transpose_kernel(const SrcT* __restrict__ in, long ld_in, bf16* __restrict__ out,
+                                                        long ld_out, long rows, int cols, float* __restrict__ colsum,
+                                                        const int* __restrict__ rows_dev) {
+  __shared__ unsigned short tile[TT][TT + 2];
+  long live = rows;
+  if (rows_dev) {
+    const long rd = *rows_dev;
+    live = rd < rows ? rd : rows;
+    // tiles entirely past the 64-row round-up of the live count are never consumed
+    if ((long)blockIdx.y * TT >= ((live + TT - 1) / TT) * TT) return;
+  }
+  const int t = threadIdx.x;
+  const long r0 = (long)blockIdx.y * TT;
+  const int c0 = blockIdx.x * TT;
+  // load: thread -> (row = t >> 3 (+32), 8 columns)
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int rr = (t >> 3) + 32 * pass;
+    const int cc = (t & 7) * 8;
+    const long r = r0 + rr;
+    unsigned short vals[8];
+    if (r < live && c0 + cc < cols) {
+      if constexpr (sizeof(SrcT) == 2) {
+        const u16x8 v = *(const u16x8*)(in + r * ld_in + c0 + cc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vals[j] = v[j];
+      } else {
+        const f32x4 a = *(const f32x4*)(in + r * ld_in + c0 + cc);
+        const f32x4 b = *(const f32x4*)(in + r * ld_in + c0 + cc + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vals[j] = bf16_bits(a[j]);
+          vals[4 + j] = bf16_bits(b[j]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vals[j] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[rr][cc + j] = vals[j];
+  }
+  __syncthreads();
+  // store: thread -> (out row = column c0 + (t >> 2), 16 source rows = 32 contiguous bytes)
+  {
+    const int oc = t >> 2;
+    const int rb = (t & 3) * 16;
+    if (c0 + oc < cols) {
+      unsigned short vals[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) vals[j] = tile[rb + j][oc];
+      bf16* dst = out + (long)(c0 + oc) * ld_out + r0 + rb;
+      u16x8 o0, o1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o0[j] = vals[j];
+        o1[j] = vals[8 + j];
+      }
+      *(u16x8*)dst = o0;
+      *(u16x8*)(dst + 8) = o1;
+    }
+  }
+  if (colsum && t < TT && c0 + t < cols) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < TT; ++r) s += bits_to_float(tile[r][t]);
+    atomicAdd(colsum + c0 + t, s);
+  }
+}
+
+inline int ew_grid(long n) {
+  long g = (n / 4 + 255) / 256;
+  if (g < 1) g = 1;
+  return (int)(g < 4096 ? g : 4096);
+}
+
+}  // namespace
+
+extern "C" int stonk_sumsq_f32(const float* x, int64_t n, float* out_accum, void* stream) {
+  STONK_CHECK_ARG(x && out_accum && n >= 0, STONK_EINVAL);
+  STONK_CHECK_ARG((uintptr_t)x % 16 == 0, STONK_EALIGN);
+  if (n == 0) return STONK_OK;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid(n) < 1024 ? ew_grid(n) : 1024), dim3(256), 0, (hipStream_t)stream, x,
+                     (long)n, out_accum);
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
+                                const float* gnorm_sq_dev, float max_grad_norm, float grad_scale, void* stream) {
+  STONK_CHECK_ARG(p && g && m && v && n >= 0 && n % 4 == 0, STONK_EINVAL);
+  STONK_CHECK_ARG(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, STONK_EALIGN);
+  STONK_CHECK_ARG(bias_corr1 > 0.f && bias_corr2 > 0.f, STONK_EINVAL);
+  if (n == 0) return STONK_OK;
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16,
+                     (long)n, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, gnorm_sq_dev, max_grad_norm,
+                     grad_scale);
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_scale_f32(float* x, int64_t n, float s, void* stream) {
+  STONK_CHECK_ARG(x && n >= 0, STONK_EINVAL);
+  if (n == 0) return STONK_OK;
+  hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, (long)n, s);
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+  STONK_CHECK_ARG(x && y && n >= 0, STONK_EINVAL);
+  STONK_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)y % 8 == 0, STONK_EALIGN);
+  if (n == 0) return STONK_OK;
+  hipLaunchKernelGGL(cast_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)y, (long)n);
+  return stonk_launch_status();
+}
+
+// out[c][r] = in[r][c] for r < rows (rows >= *rows_dev read as zero), c < cols. out needs ld_out >= roundup(rows, 64).
+extern "C" int stonk_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int cols,
+                                    float* colsum, const int* rows_dev, void* stream) {
+  STONK_CHECK_ARG(in && out && rows >= 0 && cols > 0, STONK_EINVAL);
+  STONK_CHECK_ARG(cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0, STONK_EALIGN);
+  STONK_CHECK_ARG(ld_out >= ((rows + TT - 1) / TT) * TT, STONK_ESHAPE);
+  if (rows == 0) return STONK_OK;
+  const dim3 grid((cols + TT - 1) / TT, (unsigned)((rows + TT - 1) / TT));
+  hipLaunchKernelGGL((transpose_kernel<bf16>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)in, (long)ld_in,
+                     (bf16*)out, (long)ld_out, (long)rows, cols, colsum, rows_dev);
+  return stonk_launch_status();
+}
+
+// bf16 W^T copy of a dense fp32 [rows, cols] master weight: out[c][r] = bf16(in[r][c])
+extern "C" int stonk_transpose_f32_to_bf16(const float* in, void* out, int64_t rows, int cols, int64_t ld_out,
+                                           void* stream) {
+  STONK_CHECK_ARG(in && out && rows >= 0 && cols > 0, STONK_EINVAL);
+  STONK_CHECK_ARG(cols % 8 == 0 && ld_out % 8 == 0, STONK_EALIGN);
+  STONK_CHECK_ARG(ld_out >= ((rows + TT - 1) / TT) * TT, STONK_ESHAPE);
+  if (rows == 0) return STONK_OK;
+  const dim3 grid((cols + TT - 1) / TT, (unsigned)((rows + TT - 1) / TT));
+  hipLaunchKernelGGL((transpose_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, in, (long)cols, (bf16*)out,
+                     (long)ld_out, (long)rows, cols, (float*)nullptr, (const int*)nullptr);
+  return stonk_launch_status();
+}

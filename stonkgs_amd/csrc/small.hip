@@ -1,0 +1,117 @@
+// Tiny fp32 heads of the STonKGs step (K9/K14 in SURVEY.md section 2.3): BertPooler tanh(W h[:,0] + b)
+// (hf:models/bert/modeling_bert.py:457-463) and the NSP classifier Linear(H, 2) (:523,527). M = batch rows
+// only (64 at the benchmark config), so these are latency-trivial wave-per-output dot products on the fp32
+// master weights - no bf16 rounding on the pooled path.
+#include "common.h"
+#include "stonk_flags.h"
+
+namespace {
+
+__device__ __forceinline__ float load_x(const void* x, long idx, bool f32) {
+  return f32 ? ((const float*)x)[idx] : (float)((const bf16*)x)[idx];
+}
+
+// y[m][n] = act(sum_k x[m*ldx + k] * W[n][k] + bias[n]);  one wave per (m, n)
+__global__ __launch_bounds__(256) void small_linear_fwd_kernel(const void* __restrict__ x, long ldx,
+                                                               const float* __restrict__ W,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int M, int N, int K, int act) {
+  const int lane = threadIdx.x & 63;
+  const long wave_id = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const long nw = ((long)gridDim.x * 256) >> 6;
+  const bool xf32 = act & STONK_SMALL_X_F32;
+  for (long o = wave_id; o < (long)M * N; o += nw) {
+    const int m = (int)(o / N), n = (int)(o - (long)m * N);
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc += load_x(x, (long)m * ldx + k, xf32) * W[(long)n * K + k];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      float v = acc + (bias ? bias[n] : 0.f);
+      if (act & STONK_SMALL_TANH) v = tanhf(v);
+      y[(long)m * N + n] = v;
+    }
+  }
+}
+
+// dpre = dy * (1 - y^2) for tanh, else dy.
+// dW[n][k] += sum_m dpre[m][n] x[m][k];  db[n] += sum_m dpre[m][n]     (one thread per (n, k))
+__global__ __launch_bounds__(256) void small_linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                 const void* __restrict__ x, long ldx,
+                                                                 float* __restrict__ dW, float* __restrict__ db, int M,
+                                                                 int N, int K, int act) {
+  const bool xf32 = act & STONK_SMALL_X_F32, th = act & STONK_SMALL_TANH;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)N * K; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / K), k = (int)(i - (long)n * K);
+    float acc = 0.f, accb = 0.f;
+    for (int m = 0; m < M; ++m) {
+      float d = dy[(long)m * N + n];
+      if (th) {
+        const float yy = y[(long)m * N + n];
+        d *= 1.f - yy * yy;
+      }
+      acc += d * load_x(x, (long)m * ldx + k, xf32);
+      accb += d;
+    }
+    dW[i] += acc;
+    if (k == 0 && db) db[n] += accb;
+  }
+}
+
+// dx[m][k] = sum_n dpre[m][n] W[n][k]; written as fp32 (dx_f32[m*K + k]) and/or ADDED into a bf16 row
+// (dx_bf16[m*ld_dxb + k] += ...: the pooler's gradient lands on position 0 of d(sequence_output)).
+__global__ __launch_bounds__(256) void small_linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                 const float* __restrict__ W, float* __restrict__ dx_f32,
+                                                                 bf16* __restrict__ dx_bf16, long ld_dxb, int M, int N,
+                                                                 int K, int act) {
+  const bool th = act & STONK_SMALL_TANH;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)M * K; i += (long)gridDim.x * 256) {
+    const int m = (int)(i / K), k = (int)(i - (long)m * K);
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+      float d = dy[(long)m * N + n];
+      if (th) {
+        const float yy = y[(long)m * N + n];
+        d *= 1.f - yy * yy;
+      }
+      acc += d * W[(long)n * K + k];
+    }
+    if (dx_f32) dx_f32[i] = acc;
+    if (dx_bf16) {
+      bf16* p = dx_bf16 + (long)m * ld_dxb + k;
+      *p = (bf16)((float)*p + acc);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int stonk_small_linear_fwd(const void* x, int64_t ldx, const float* W, const float* bias, float* y, int M,
+                                      int N, int K, int act, void* stream) {
+  STONK_CHECK_ARG(x && W && y, STONK_EINVAL);
+  STONK_CHECK_ARG(M >= 0 && N > 0 && K > 0 && ldx >= K, STONK_ESHAPE);
+  if (M == 0) return STONK_OK;
+  long waves = (long)M * N;
+  int grid = (int)((waves + 3) / 4 < 2048 ? (waves + 3) / 4 : 2048);
+  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, W, bias, y, M,
+                     N, K, act);
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_small_linear_bwd(const float* dy, const float* y, const void* x, int64_t ldx, const float* W,
+                                      float* dW, float* db, float* dx_f32, void* dx_bf16_accum, int64_t ld_dxb, int M,
+                                      int N, int K, int act, void* stream) {
+  STONK_CHECK_ARG(dy && x && W && dW, STONK_EINVAL);
+  STONK_CHECK_ARG(!(act & STONK_SMALL_TANH) || y, STONK_EINVAL);
+  STONK_CHECK_ARG(M >= 0 && N > 0 && K > 0 && ldx >= K, STONK_ESHAPE);
+  if (M == 0) return STONK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  long nk = (long)N * K;
+  hipLaunchKernelGGL(small_linear_wgrad_kernel, dim3((unsigned)((nk + 255) / 256 < 4096 ? (nk + 255) / 256 : 4096)),
+                     dim3(256), 0, st, dy, y, x, (long)ldx, dW, db, M, N, K, act);
+  if (dx_f32 || dx_bf16_accum) {
+    long mk = (long)M * K;
+    hipLaunchKernelGGL(small_linear_dgrad_kernel, dim3((unsigned)((mk + 255) / 256 < 4096 ? (mk + 255) / 256 : 4096)),
+                       dim3(256), 0, st, dy, y, W, dx_f32, (bf16*)dx_bf16_accum, (long)ld_dxb, M, N, K, act);
+  }
+  return stonk_launch_status();
+}

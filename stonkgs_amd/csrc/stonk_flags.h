@@ -14,3 +14,6 @@
 #define STONK_EPI_DEBUG_REGSTAGE (1 << 16) /* A/B test: register staging instead of LDS-DMA */
 // --- stonk_layernorm_* `flags` ---
 #define STONK_LN_DROPOUT (1 << 0)
+// --- stonk_small_linear_* `act` ---
+#define STONK_SMALL_TANH 1
+#define STONK_SMALL_X_F32 16 /* x is fp32 (default bf16) */

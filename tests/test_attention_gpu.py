@@ -1,0 +1,132 @@
+"""GPU parity: fused attention forward/backward (C-ABI stonk_attention_fwd/bwd) against a torch fp32 reference
+computed from the same bf16 inputs (the eager path of hf BertSelfAttention: softmax(QK^T/8 + mask) V)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(qkv, mask, B, S, NH, dout=None):
+    H = NH * 64
+    x = qkv.float().view(B, S, 3, NH, 64).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)  # [3,B,NH,S,64]
+    q, k, v = x[0], x[1], x[2]
+    s = q @ k.transpose(-1, -2) / 8.0
+    if mask is not None:
+        s = s + (1.0 - mask.float())[:, None, None, :] * torch.finfo(torch.float32).min
+    p = torch.softmax(s, -1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B * S, H)
+    lse = torch.logsumexp(s, -1)
+    grads = None
+    if dout is not None:
+        o.backward(dout.float())
+        grads = x.grad.permute(1, 3, 0, 2, 4).reshape(B * S, 3 * H)
+    return o.detach(), lse.detach(), grads
+
+
+def _run_fwd(hip, qkv, mask, B, S, NH, drop_p=0.0, seed=0):
+    H = NH * 64
+    out = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, NH, S, device="cuda")
+    hip.call("stonk_attention_fwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask),
+             hip.ptr(out), H, hip.ptr(lse), B, NH, S, 64, 0.125, drop_p, seed, hip.stream_ptr())
+    return out, lse
+
+
+def _run_bwd(hip, qkv, mask, out, dout, lse, B, S, NH, drop_p=0.0, seed=0):
+    H = NH * 64
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.empty(B, NH, S, device="cuda")
+    hip.call("stonk_attention_bwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask),
+             hip.ptr(out), H, hip.ptr(dout), H, hip.ptr(lse), hip.ptr(delta), hip.ptr(dqkv), hip.ptr(dqkv) + 2 * H,
+             3 * H, hip.ptr(dqkv) + 4 * H, B, NH, S, 64, 0.125, drop_p, seed, hip.stream_ptr())
+    return dqkv
+
+
+def _inputs(B, S, NH, seed, masked):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    H = NH * 64
+    qkv = (torch.randn(B * S, 3 * H, device="cuda", generator=g) * 1.5).to(torch.bfloat16)
+    dout = torch.randn(B * S, H, device="cuda", generator=g).to(torch.bfloat16)
+    mask = None
+    if masked:
+        lens = torch.randint(S // 8, S // 2, (B,), generator=torch.Generator().manual_seed(seed))
+        mask = torch.ones(B, S, dtype=torch.long)
+        for b in range(B):
+            mask[b, lens[b]: S // 2] = 0  # padded text half, entity half all ones (the STonKGs layout)
+        mask = mask.cuda()
+    return qkv, dout, mask
+
+
+def _relerr(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm()).item()
+
+
+@pytest.mark.parametrize("B,S,NH,masked", [(1, 128, 1, False), (2, 256, 2, True), (3, 512, 12, True), (2, 256, 3, False)])
+def test_attention_fwd_bwd(hip, B, S, NH, masked):
+    qkv, dout, mask = _inputs(B, S, NH, 11 + S, masked)
+    o_ref, lse_ref, g_ref = _ref(qkv, mask, B, S, NH, dout)
+    out, lse = _run_fwd(hip, qkv, mask, B, S, NH)
+    torch.cuda.synchronize()
+    assert _relerr(out, o_ref) < 1e-2, _relerr(out, o_ref)
+    torch.testing.assert_close(out.float(), o_ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(lse, lse_ref, rtol=1e-4, atol=2e-3)
+    dqkv = _run_bwd(hip, qkv, mask, out, dout, lse, B, S, NH)
+    torch.cuda.synchronize()
+    H = NH * 64
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        e = _relerr(dqkv[:, sl], g_ref[:, sl])
+        assert e < 2e-2, (name, e)
+    # deterministic: no atomics anywhere in the attention path
+    dqkv2 = _run_bwd(hip, qkv, mask, out, dout, lse, B, S, NH)
+    assert torch.equal(dqkv, dqkv2)
+
+
+def test_attention_spike_forces_online_rescale(hip):
+    """One key per tile dominates a query: exercises the running-max rescale branch (guide rule 26)."""
+    B, S, NH = 1, 256, 1
+    qkv, dout, _ = _inputs(B, S, NH, 5, False)
+    q = qkv.float().clone()
+    for t, key in enumerate((70, 130, 200)):  # later tiles carry ever larger maxima for query 3
+        q[key, 64:128] = q[3, 0:64] * (2.0 + t)
+    qkv = q.to(torch.bfloat16)
+    o_ref, lse_ref, _ = _ref(qkv, None, B, S, NH)
+    out, lse = _run_fwd(hip, qkv, None, B, S, NH)
+    torch.testing.assert_close(out.float(), o_ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(lse, lse_ref, rtol=1e-4, atol=2e-3)
+
+
+def test_attention_dropout_statistics_and_replay(hip):
+    B, S, NH = 2, 256, 2
+    qkv, dout, mask = _inputs(B, S, NH, 21, True)
+    o0, lse0 = _run_fwd(hip, qkv, mask, B, S, NH)
+    o1, lse1 = _run_fwd(hip, qkv, mask, B, S, NH, 0.1, 5)
+    o2, _ = _run_fwd(hip, qkv, mask, B, S, NH, 0.1, 5)
+    assert torch.equal(o1, o2)
+    torch.testing.assert_close(lse0, lse1)  # statistics are taken before dropout
+    # E[dropout(P)] = P: averaging many seeds converges to the undropped output
+    acc = torch.zeros_like(o0, dtype=torch.float32)
+    n = 64
+    for s in range(n):
+        acc += _run_fwd(hip, qkv, mask, B, S, NH, 0.1, 100 + s)[0].float()
+    assert _relerr(acc / n, o0) < 0.08
+    # backward replays the forward's mask: finite-difference-free check via linearity in dout for dV
+    g1 = _run_bwd(hip, qkv, mask, o1, dout, lse1, B, S, NH, 0.1, 5)
+    g2 = _run_bwd(hip, qkv, mask, o1, dout, lse1, B, S, NH, 0.1, 5)
+    assert torch.equal(g1, g2)
+    H = NH * 64
+    # dV = dropped(P)^T dO: compare with torch using the mask recovered from o1 is not possible, so check
+    # against the expectation instead: mean over seeds of dV converges to the undropped dV
+    _, _, g_ref = _ref(qkv, mask, B, S, NH, dout)
+    accv = torch.zeros(B * S, H, device="cuda")
+    for s in range(n):
+        o_s, lse_s = _run_fwd(hip, qkv, mask, B, S, NH, 0.1, 100 + s)
+        accv += _run_bwd(hip, qkv, mask, o_s, dout, lse_s, B, S, NH, 0.1, 100 + s)[:, 2 * H:].float()
+    assert _relerr(accv / n, g_ref[:, 2 * H:]) < 0.1
+
+
+def test_attention_bad_shape(hip):
+    qkv = torch.zeros(100, 192, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(hip.StonkHipError):
+        _run_fwd(hip, qkv, None, 1, 100, 1)

@@ -8,14 +8,14 @@ pytestmark = pytest.mark.gpu
 
 
 def _gemm(hip, A, B, out_dtype=torch.bfloat16, M=None, flags=0, bias=None, resid=None, aux=None, alpha=1.0,
-          split_k=1, C=None, m_dev=None, drop_p=0.0, seed=0):
+          split_k=1, C=None, m_dev=None, k_dev=None, drop_p=0.0, seed=0):
     M = A.shape[0] if M is None else M
     N, K = B.shape
     if C is None:
         C = torch.empty(M, N, device=A.device, dtype=out_dtype)
     hip.call("stonk_gemm_nt_bf16", hip.ptr(A), A.stride(0), hip.ptr(B), B.stride(0), hip.ptr(C), C.stride(0), M, N, K,
              flags, hip.ptr(bias), hip.ptr(resid), 0 if resid is None else resid.stride(0), hip.ptr(aux),
-             0 if aux is None else aux.stride(0), alpha, split_k, hip.ptr(m_dev), drop_p, seed, hip.stream_ptr())
+             0 if aux is None else aux.stride(0), alpha, split_k, hip.ptr(m_dev), hip.ptr(k_dev), drop_p, seed, hip.stream_ptr())
     return C
 
 

@@ -1,0 +1,198 @@
+"""GPU parity for the HBM-bound helper kernels: transposes, label compaction, gather/scatter, fused softmax
+cross-entropy, NSP loss, pooler/NSP heads, grad-norm + AdamW."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, scale=1.0, seed=0, dtype=torch.bfloat16):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, device="cuda", generator=g) * scale).to(dtype)
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 64), (1000, 768), (130, 2304)])
+def test_transpose_bf16_colsum(hip, rows, cols):
+    x = _rand((rows, cols), 1.0, 1)
+    rpad = (rows + 63) // 64 * 64
+    out = torch.full((cols, rpad), 7.0, device="cuda", dtype=torch.bfloat16)
+    cs = torch.zeros(cols, device="cuda")
+    hip.call("stonk_transpose_bf16", hip.ptr(x), cols, hip.ptr(out), rpad, rows, cols, hip.ptr(cs), 0, hip.stream_ptr())
+    assert torch.equal(out[:, :rows], x.t())
+    assert (out[:, rows:] == 0).all()
+    torch.testing.assert_close(cs, x.float().sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_transpose_device_row_count(hip):
+    rows, cols, live = 1024, 128, 300
+    x = _rand((rows, cols), 1.0, 2)
+    out = torch.full((cols, rows), 7.0, device="cuda", dtype=torch.bfloat16)
+    cnt = torch.tensor([live], device="cuda", dtype=torch.int32)
+    hip.call("stonk_transpose_bf16", hip.ptr(x), cols, hip.ptr(out), rows, rows, cols, 0, hip.ptr(cnt), hip.stream_ptr())
+    assert torch.equal(out[:, :live], x[:live].t())
+    assert (out[:, live:320] == 0).all()  # zero up to the 64-row round-up: what a K tile of the wgrad GEMM reads
+
+
+def test_transpose_f32_and_cast(hip):
+    w = _rand((1000, 256), 0.02, 3, torch.float32)
+    out = torch.full((256, 1024), 7.0, device="cuda", dtype=torch.bfloat16)
+    hip.call("stonk_transpose_f32_to_bf16", hip.ptr(w), hip.ptr(out), 1000, 256, 1024, hip.stream_ptr())
+    assert torch.equal(out[:, :1000], w.to(torch.bfloat16).t())
+    assert (out[:, 1000:] == 0).all()
+    y = torch.empty(1000 * 256 - 3, device="cuda", dtype=torch.bfloat16)
+    hip.call("stonk_cast_f32_to_bf16", hip.ptr(w), hip.ptr(y), y.numel(), hip.stream_ptr())
+    assert torch.equal(y, w.flatten()[: y.numel()].to(torch.bfloat16))
+
+
+def test_label_compact_gather_scatter(hip):
+    B, half, S, H = 5, 256, 512, 64
+    g = torch.Generator().manual_seed(0)
+    labels = torch.full((B, half), -100, dtype=torch.long)
+    pick = torch.rand(B, half, generator=g) < 0.15
+    labels[pick] = torch.randint(0, 1000, (int(pick.sum()),), generator=g)
+    labels = labels.cuda()
+    n = B * half
+    rows = torch.full((n,), -1, device="cuda", dtype=torch.int32)
+    tg = torch.full((n,), -1, device="cuda", dtype=torch.int32)
+    cnt = torch.zeros(1, device="cuda", dtype=torch.int32)
+    hip.call("stonk_label_compact", hip.ptr(labels), n, half, S, half, hip.ptr(rows), hip.ptr(tg), hip.ptr(cnt),
+             hip.stream_ptr())
+    idx = (labels.view(-1) != -100).nonzero().squeeze(1)
+    c = cnt.item()
+    assert c == idx.numel()
+    exp_rows = (idx // half) * S + half + idx % half
+    assert torch.equal(rows[:c].long(), exp_rows)
+    assert torch.equal(tg[:c].long(), labels.view(-1)[idx])
+    # gather / scatter
+    src = _rand((B * S, H), 1.0, 4)
+    cap = n
+    dst = torch.full((cap, H), 9.0, device="cuda", dtype=torch.bfloat16)
+    hip.call("stonk_gather_rows_bf16", hip.ptr(src), H, hip.ptr(rows), hip.ptr(cnt), hip.ptr(dst), H, H, cap,
+             hip.stream_ptr())
+    assert torch.equal(dst[:c], src[exp_rows])
+    lim = (c + 127) // 128 * 128
+    assert (dst[c:lim] == 0).all()
+    back = torch.zeros_like(src)
+    hip.call("stonk_scatter_rows_bf16", hip.ptr(dst), H, hip.ptr(rows), hip.ptr(cnt), hip.ptr(back), H, H,
+             hip.stream_ptr())
+    ref = torch.zeros_like(src)
+    ref[exp_rows] = src[exp_rows]
+    assert torch.equal(back, ref)
+
+
+@pytest.mark.parametrize("N", [1000, 28996])
+def test_softmax_xent(hip, N):
+    R, cap = 37, 128
+    npad = (N + 127) // 128 * 128
+    logits = torch.zeros(cap, npad, device="cuda")
+    logits[:, :N] = _rand((cap, N), 3.0, 5, torch.float32)
+    tg = torch.randint(0, N, (cap,), device="cuda", dtype=torch.int32)
+    cnt = torch.tensor([R], device="cuda", dtype=torch.int32)
+    loss = torch.zeros(1, device="cuda")
+    dl = torch.full((cap, npad), 5.0, device="cuda", dtype=torch.bfloat16)
+    err = torch.zeros(1, device="cuda", dtype=torch.int32)
+    hip.call("stonk_softmax_xent_fwd_bwd", hip.ptr(logits), npad, N, npad, hip.ptr(tg), hip.ptr(cnt), hip.ptr(loss),
+             hip.ptr(dl), npad, 1.0, hip.ptr(err), hip.stream_ptr())
+    x = logits[:R, :N].clone().requires_grad_(True)
+    ref = F.cross_entropy(x, tg[:R].long())
+    ref.backward()
+    torch.testing.assert_close(loss[0] / R, ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dl[:R, :N].float(), x.grad, rtol=1e-2, atol=1e-5)
+    assert (dl[:R, N:] == 0).all()
+    assert err.item() == 0
+
+
+def test_nsp_and_finalize(hip):
+    B = 64
+    logits = _rand((B, 2), 1.0, 6, torch.float32)
+    labels = torch.randint(0, 2, (B,), device="cuda")
+    acc = torch.zeros(2, device="cuda")
+    dl = torch.empty(B, 2, device="cuda")
+    err = torch.zeros(1, device="cuda", dtype=torch.int32)
+    hip.call("stonk_nsp_xent_fwd_bwd", hip.ptr(logits), hip.ptr(labels), B, 2, hip.ptr(acc), hip.ptr(dl), 1.0,
+             hip.ptr(err), hip.stream_ptr())
+    x = logits.clone().requires_grad_(True)
+    ref = F.cross_entropy(x, labels)
+    ref.backward()
+    torch.testing.assert_close(acc[0] / acc[1], ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dl, x.grad, rtol=1e-4, atol=1e-6)
+    ts = torch.tensor([10.0], device="cuda")
+    tc = torch.tensor([4], device="cuda", dtype=torch.int32)
+    es = torch.tensor([9.0], device="cuda")
+    ec = torch.tensor([3], device="cuda", dtype=torch.int32)
+    out = torch.zeros(4, device="cuda")
+    hip.call("stonk_loss_finalize", hip.ptr(ts), hip.ptr(tc), hip.ptr(es), hip.ptr(ec), hip.ptr(acc), hip.ptr(out),
+             hip.stream_ptr())
+    torch.testing.assert_close(out, torch.stack([2.5 + 3.0 + ref.detach(), torch.tensor(2.5, device="cuda"),
+                                                 torch.tensor(3.0, device="cuda"), ref.detach()]))
+
+
+def test_small_linear_fwd_bwd(hip):
+    B, S, H = 6, 4, 128
+    seq = _rand((B * S, H), 1.0, 7)
+    W = _rand((H, H), 0.05, 8, torch.float32)
+    b = _rand((H,), 0.05, 9, torch.float32)
+    y = torch.empty(B, H, device="cuda")
+    hip.call("stonk_small_linear_fwd", hip.ptr(seq), S * H, hip.ptr(W), hip.ptr(b), hip.ptr(y), B, H, H, hip.SMALL_TANH,
+             hip.stream_ptr())
+    x0 = seq.view(B, S, H)[:, 0].float().requires_grad_(True)
+    Wr, br = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.tanh(x0 @ Wr.t() + br)
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-5)
+    dy = _rand((B, H), 1.0, 10, torch.float32)
+    ref.backward(dy)
+    dW = torch.zeros_like(W)
+    db = torch.zeros_like(b)
+    dseq = _rand((B * S, H), 1.0, 11)
+    dseq0 = dseq.clone()
+    hip.call("stonk_small_linear_bwd", hip.ptr(dy), hip.ptr(y), hip.ptr(seq), S * H, hip.ptr(W), hip.ptr(dW), hip.ptr(db),
+             0, hip.ptr(dseq), S * H, B, H, H, hip.SMALL_TANH, hip.stream_ptr())
+    torch.testing.assert_close(dW, Wr.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(db, br.grad, rtol=1e-4, atol=1e-5)
+    got = dseq.view(B, S, H)[:, 0].float() - dseq0.view(B, S, H)[:, 0].float()
+    torch.testing.assert_close(got, x0.grad, rtol=5e-2, atol=3e-2)  # bf16 read-modify-write
+    assert torch.equal(dseq.view(B, S, H)[:, 1:], dseq0.view(B, S, H)[:, 1:])
+    # fp32-input classifier without activation
+    W2 = _rand((2, H), 0.05, 12, torch.float32)
+    b2 = _rand((2,), 0.05, 13, torch.float32)
+    y2 = torch.empty(B, 2, device="cuda")
+    hip.call("stonk_small_linear_fwd", hip.ptr(y), H, hip.ptr(W2), hip.ptr(b2), hip.ptr(y2), B, 2, H, hip.SMALL_X_F32,
+             hip.stream_ptr())
+    torch.testing.assert_close(y2, y @ W2.t() + b2, rtol=1e-4, atol=1e-5)
+    dx = torch.empty(B, H, device="cuda")
+    dW2 = torch.zeros_like(W2)
+    db2 = torch.zeros_like(b2)
+    dy2 = _rand((B, 2), 1.0, 14, torch.float32)
+    hip.call("stonk_small_linear_bwd", hip.ptr(dy2), 0, hip.ptr(y), H, hip.ptr(W2), hip.ptr(dW2), hip.ptr(db2),
+             hip.ptr(dx), 0, 0, B, 2, H, hip.SMALL_X_F32, hip.stream_ptr())
+    torch.testing.assert_close(dx, dy2 @ W2, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dW2, dy2.t() @ y, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(db2, dy2.sum(0), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("clip", [False, True])
+def test_adamw_matches_torch(hip, clip):
+    n = 4096 * 3 + 8
+    p0 = _rand((n,), 0.05, 15, torch.float32)
+    scale = 30.0 if clip else 0.01
+    grads = [_rand((n,), scale, 16 + i, torch.float32) for i in range(3)]
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pb = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    for step, g in enumerate(grads, 1):
+        ref_p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        gg = g.clone()
+        nrm = torch.zeros(1, device="cuda")
+        hip.call("stonk_sumsq_f32", hip.ptr(gg), n, hip.ptr(nrm), hip.stream_ptr())
+        torch.testing.assert_close(nrm[0], (g.double() ** 2).sum().float(), rtol=1e-5, atol=0)
+        hip.call("stonk_adamw_step", hip.ptr(p), hip.ptr(gg), hip.ptr(m), hip.ptr(v), hip.ptr(pb), n, 1e-3, 0.9, 0.999,
+                 1e-8, 0.01, 1 - 0.9 ** step, 1 - 0.999 ** step, hip.ptr(nrm), 1.0, 1.0, hip.stream_ptr())
+        assert (gg == 0).all()  # zero_grad fused
+        torch.testing.assert_close(p, ref_p.data, rtol=2e-5, atol=2e-7)
+        assert torch.equal(pb, p.to(torch.bfloat16))

@@ -32,7 +32,7 @@ def bench_gemm():
         for name, dbg in (("glds", 0), ("regstage", hip.EPI_DEBUG_REGSTAGE)):
             def f():
                 hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, M, N, K, dbg, 0, 0, 0, 0, 0,
-                         1.0, 1, 0, 0.0, 0, hip.stream_ptr())
+                         1.0, 1, 0, 0, 0.0, 0, hip.stream_ptr())
             t = timeit(f)
             print(f"gemm {M}x{N}x{K} {name}: {t*1e6:.1f} us  {2*M*N*K/t/1e12:.1f} TF/s", flush=True)
         t = timeit(lambda: torch.matmul(A, B.t()))
@@ -45,7 +45,7 @@ def bench_gemm():
         C = torch.zeros(Mo, No, device="cuda")
         def f():
             hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), No, Mo, No, K,
-                     hip.EPI_OUT_F32_ATOMIC, 0, 0, 0, 0, 0, 1.0, sk, 0, 0.0, 0, hip.stream_ptr())
+                     hip.EPI_OUT_F32_ATOMIC, 0, 0, 0, 0, 0, 1.0, sk, 0, 0, 0.0, 0, hip.stream_ptr())
         t = timeit(f)
         print(f"wgrad {Mo}x{No}x{K} splitk={sk}: {t*1e6:.1f} us  {2*Mo*No*K/t/1e12:.1f} TF/s", flush=True)
 
@@ -67,6 +67,35 @@ def bench_ln():
     t = timeit(lambda: hip.call("stonk_layernorm_bwd", hip.ptr(y), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(g),
                                 hip.ptr(dx), 0, hip.ptr(dg), hip.ptr(db), rows, H, 0, 0.0, 0, 0.0, 0, hip.stream_ptr()))
     print(f"layernorm_bwd {rows}x{H}: {t*1e6:.1f} us  {rows*H*6/t/1e9:.0f} GB/s", flush=True)
+
+
+
+
+def bench_attn():
+    B, S, NH = 64, 512, 12
+    H = NH * 64
+    qkv = (torch.randn(B * S, 3 * H, device="cuda")).to(torch.bfloat16)
+    dout = torch.randn(B * S, H, device="cuda").to(torch.bfloat16)
+    mask = torch.ones(B, S, dtype=torch.long, device="cuda")
+    mask[:, 200:256] = 0
+    out = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, NH, S, device="cuda")
+    delta = torch.empty(B, NH, S, device="cuda")
+    dqkv = torch.empty_like(qkv)
+    for p in (0.0, 0.1):
+        def f():
+            hip.call("stonk_attention_fwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H,
+                     hip.ptr(mask), hip.ptr(out), H, hip.ptr(lse), B, NH, S, 64, 0.125, p, 1, hip.stream_ptr())
+        t = timeit(f)
+        fl = 4.0 * B * NH * S * S * 64
+        print(f"attn_fwd B{B} S{S} NH{NH} p={p}: {t*1e6:.1f} us  {fl/t/1e12:.1f} TF/s", flush=True)
+        def g():
+            hip.call("stonk_attention_bwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H,
+                     hip.ptr(mask), hip.ptr(out), H, hip.ptr(dout), H, hip.ptr(lse), hip.ptr(delta), hip.ptr(dqkv),
+                     hip.ptr(dqkv) + 2 * H, 3 * H, hip.ptr(dqkv) + 4 * H, B, NH, S, 64, 0.125, p, 1, hip.stream_ptr())
+        t = timeit(g)
+        print(f"attn_bwd B{B} S{S} NH{NH} p={p}: {t*1e6:.1f} us  {2.5*fl/t/1e12:.1f} TF/s (algorithmic 10*B*NH*S^2*D)",
+              flush=True)
 
 
 if __name__ == "__main__":

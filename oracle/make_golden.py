@@ -1,0 +1,238 @@
+"""Generate the golden vectors under tests/golden/ FROM THE REFERENCE ITSELF  (authoring container only).
+
+TEST INFRASTRUCTURE. Reads /root/reference at run time (never copies it): imports the reference's
+``stonkgs.models.stonkgs_model`` and ``stonkgs.data.indra_for_pretraining`` unmodified, with the package
+``__init__`` files and the network-touching ``stonkgs.constants`` replaced by stubs (recipe: SURVEY.md
+Appendix A), builds the reference model from a LOCAL BertConfig with seeded random weights, runs the
+reference's own ``forward`` / HF BERT / torch AdamW on CPU, and stores inputs + expected outputs as arrays.
+
+Nothing here runs on the GPU box; the fixtures it writes are data only (ints / floats / config numbers).
+
+    python oracle/make_golden.py          # rewrites tests/golden/*.npz, *.json
+"""
+from __future__ import annotations
+
+import importlib
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import stonkgs_oracle as orc  # noqa: E402
+
+REF = "/root/reference/src/stonkgs"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    for name, path in (("stonkgs", REF), ("stonkgs.models", REF + "/models"), ("stonkgs.data", REF + "/data")):
+        pkg = types.ModuleType(name)
+        pkg.__path__ = [path]  # namespace stub: skips every __init__.py (pybel / pystow / network)
+        sys.modules[name] = pkg
+    const = types.ModuleType("stonkgs.constants")
+    for k in ("EMBEDDINGS_PATH", "NLP_MODEL_TYPE", "PRETRAINING_DIR", "PRETRAINING_PATH", "RANDOM_WALKS_PATH",
+              "VOCAB_FILE"):
+        setattr(const, k, "/nonexistent/" + k)
+    sys.modules["stonkgs.constants"] = const
+    kgb = types.ModuleType("stonkgs.models.kg_baseline_model")
+    kgb.prepare_df = lambda path, sep="\t": {}  # never called: the hub-fetching __init__ is bypassed
+    sys.modules["stonkgs.models.kg_baseline_model"] = kgb
+    sm = importlib.import_module("stonkgs.models.stonkgs_model")
+    pre = importlib.import_module("stonkgs.data.indra_for_pretraining")
+    return sm, pre
+
+
+def build_reference_model(sm, cfg: orc.OracleConfig, sd, tsv_rows):
+    from transformers import BertConfig, BertForPreTraining, BertModel
+
+    hf_cfg = BertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+                        num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                        intermediate_size=cfg.intermediate_size, max_position_embeddings=cfg.max_position_embeddings,
+                        type_vocab_size=cfg.type_vocab_size, layer_norm_eps=cfg.layer_norm_eps,
+                        hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, attn_implementation="eager")
+    hf_cfg.update({"kg_vocab_size": cfg.kg_vocab_size})
+
+    class RefModel(sm.STonKGsForPreTraining):  # only the hub-fetching __init__ is replaced; forward is the reference's
+        def __init__(self, c):
+            BertForPreTraining.__init__(self, c)
+            self.cls.predictions = sm.STonKGsELMPredictionHead(c)
+            self.lm_backbone = BertModel(c)
+            for p in self.lm_backbone.parameters():
+                p.requires_grad = False
+            self.lm_sep_id, self.lm_mask_id, self.lm_unk_id = 102, 103, 100
+
+    model = RefModel(hf_cfg)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    bad = [k for k in missing if "position_ids" not in k and "decoder" not in k]
+    assert not bad and not unexpected, (bad, unexpected)
+    model.eval()
+    # kg_backbone exactly as ref:stonkgs_model.py:123-141 builds it (TSV order -> numeric_indices, then specials)
+    K = cfg.kg_vocab_size
+    numeric_indices = list(range(K + 3))
+    for sid in (102, 103, 100):
+        numeric_indices.remove(sid)
+    model.kg_backbone = {i: torch.tensor(tsv_rows[r].numpy()) for r, i in enumerate(numeric_indices)}
+    with torch.no_grad():
+        for sid in (102, 103, 100):
+            model.kg_backbone[sid] = model.lm_backbone(torch.tensor([[sid]]))[0][0][0]
+    return model
+
+
+def make_batch(cfg, B, seed, pre, pad_rows=True):
+    """Synthetic batch in the reference's schema; masking by the REFERENCE's replace_mlm_tokens."""
+    half = cfg.half_length
+    rng = np.random.RandomState(seed)
+    random.seed(seed)
+    ids, am, tt, ml, el = [], [], [], [], []
+    for b in range(B):
+        n_real = half if not pad_rows or b == 0 else int(rng.randint(half // 4, half))
+        text = [101] + list(rng.randint(104, cfg.vocab_size, n_real - 2)) + [102]
+        walk = list(rng.randint(0, cfg.kg_vocab_size, half // 2 - 1)) + [102]
+        ent = walk + list(rng.randint(0, cfg.kg_vocab_size, half // 2 - 1)) + [102]
+        t_in, t_lab = pre.replace_mlm_tokens(tokens=[int(x) for x in text], vocab_len=cfg.vocab_size)
+        e_in, e_lab = pre.replace_mlm_tokens(tokens=[int(x) for x in ent], vocab_len=cfg.kg_vocab_size)
+        pad = half - n_real
+        ids.append(t_in + [0] * pad + e_in)
+        am.append([1] * n_real + [0] * pad + [1] * half)
+        tt.append([0] * half + [1] * half)
+        ml.append(t_lab + [-100] * pad)
+        el.append(e_lab)
+    nsp = [int(x) for x in rng.randint(0, 2, B)]
+    return {"input_ids": torch.tensor(ids), "attention_mask": torch.tensor(am), "token_type_ids": torch.tensor(tt),
+            "masked_lm_labels": torch.tensor(ml), "ent_masked_lm_labels": torch.tensor(el),
+            "next_sentence_labels": torch.tensor(nsp)}
+
+
+GRAD_KEYS = ["bert.encoder.layer.0.attention.self.query.weight", "bert.encoder.layer.0.attention.self.key.bias",
+             "bert.embeddings.position_embeddings.weight", "bert.embeddings.token_type_embeddings.weight",
+             "bert.embeddings.LayerNorm.weight", "bert.pooler.dense.weight", "cls.seq_relationship.weight",
+             "cls.predictions.transform.dense.weight", "cls.predictions.transform.LayerNorm.bias",
+             "cls.predictions.text_decoder.weight", "cls.predictions.entity_decoder.weight"]
+
+
+def model_case(name, sm, pre, cfg: orc.OracleConfig, B, seed, full_logits):
+    sd = orc.init_state_dict(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    tsv_rows = (torch.randn(cfg.kg_vocab_size, cfg.hidden_size, generator=g, dtype=torch.float64) * 0.3)
+    model = build_reference_model(sm, cfg, sd, tsv_rows)
+    last = f"bert.encoder.layer.{cfg.num_hidden_layers - 1}.output.dense.bias"
+    grad_keys = GRAD_KEYS + [last]
+    batch = make_batch(cfg, B, seed + 2, pre)
+    out = model(**batch, return_dict=True)
+    tup = model(**batch)  # return_dict falsy -> tuple (quirk Q8)
+    assert torch.equal(tup[0], out.loss) and torch.equal(tup[1][1], out.prediction_logits[1])
+    model.zero_grad()
+    out.loss.backward()
+    params = dict(model.named_parameters())
+    dead = [k for k, p in params.items() if p.requires_grad and p.grad is None]
+    arrays = {k: v.numpy() for k, v in batch.items()}
+    with torch.no_grad():
+        half = cfg.half_length
+        lt = torch.nn.functional.cross_entropy(out.prediction_logits[0].reshape(-1, cfg.vocab_size),
+                                               batch["masked_lm_labels"].reshape(-1))
+        le = torch.nn.functional.cross_entropy(out.prediction_logits[1].reshape(-1, cfg.kg_vocab_size),
+                                               batch["ent_masked_lm_labels"].reshape(-1))
+        ln = torch.nn.functional.cross_entropy(out.seq_relationship_logits, batch["next_sentence_labels"])
+        arrays.update(loss=out.loss.numpy(), masked_lm_loss=lt.numpy(), ent_masked_lm_loss=le.numpy(),
+                      next_sentence_loss=ln.numpy(), nsp_logits=out.seq_relationship_logits.numpy(),
+                      pooler_output=out.pooler_output.numpy())
+        hs = out.hidden_states
+        tl, el = out.prediction_logits
+        if full_logits:
+            arrays.update(hidden_states=hs.numpy(), text_logits=tl.numpy(), ent_logits=el.numpy())
+        else:  # keep the fixture small: labelled rows + a strided sample
+            arrays.update(hidden_states_s=hs[:, ::7, ::3].numpy(),
+                          text_logits_lab=tl[batch["masked_lm_labels"] != -100].numpy(),
+                          ent_logits_lab=el[batch["ent_masked_lm_labels"] != -100].numpy(),
+                          text_logits_s=tl[:, ::5, ::3].numpy(), ent_logits_s=el[:, ::5, ::3].numpy())
+        # the special-token vectors of quirk Q2 and two gathered rows of the entity half
+        for sid in (100, 102, 103):
+            arrays[f"special_{sid}"] = model.kg_backbone[sid].numpy()
+    for k in grad_keys:
+        arrays["grad::" + k] = params[k].grad.numpy()
+    total_norm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values() if p.grad is not None))
+    arrays["grad_norm"] = np.float32(total_norm.item())
+
+    # G5: two optimizer steps exactly as the reference's Trainer configures them (hf:trainer.py:1780-1796)
+    from transformers import get_linear_schedule_with_warmup
+
+    train_params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(train_params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    sched = get_linear_schedule_with_warmup(opt, 0, 200)
+    step_losses = []
+    for _ in range(2):
+        model.zero_grad()
+        loss = model(**batch)[0]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(train_params, 1.0)
+        opt.step()
+        sched.step()
+        step_losses.append(loss.item())
+    arrays["step_losses"] = np.array(step_losses, dtype=np.float32)
+    for k in grad_keys:
+        arrays["after2::" + k] = params[k].detach().numpy()
+    meta = {"config": {k: getattr(cfg, k) for k in ("vocab_size", "kg_vocab_size", "hidden_size", "num_hidden_layers",
+                                                    "num_attention_heads", "intermediate_size",
+                                                    "max_position_embeddings", "type_vocab_size", "layer_norm_eps")},
+            "B": B, "weight_seed": seed, "table_seed": seed + 1, "batch_seed": seed + 2, "table_std": 0.3,
+            "weights_checksum": float(sum(v.double().abs().sum() for v in sd.values())),
+            "table_checksum": float(tsv_rows.abs().sum()), "dead_parameters": sorted(dead), "grad_keys": grad_keys,
+            "torch": torch.__version__}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(name, "loss", float(out.loss), "grad_norm", float(total_norm), "dead", len(dead))
+
+
+def masking_case(pre):
+    """G3/G4: integer-exact masking vectors and the entity index-space table."""
+    res = {}
+    for seed in (0, 1, 1234):
+        random.seed(seed)
+        t_in, t_lab = pre.replace_mlm_tokens(tokens=list(range(1000, 1256)), vocab_len=28996)
+        e_in, e_lab = pre.replace_mlm_tokens(tokens=[(7 * i) % 175094 for i in range(256)], vocab_len=175094)
+        res[f"text_in_{seed}"] = np.array(t_in)
+        res[f"text_lab_{seed}"] = np.array(t_lab)
+        res[f"ent_in_{seed}"] = np.array(e_in)
+        res[f"ent_lab_{seed}"] = np.array(e_lab)
+        # NSP negatives: the two random.sample draws of _add_negative_nsp_samples (ref :88-98), same order
+        import pandas as pd
+
+        random.seed(seed)
+        df = pd.DataFrame({"input_ids": [list(range(i * 10, i * 10 + 8)) for i in range(8)],
+                           "attention_mask": [[1] * 8] * 8, "token_type_ids": [[0] * 4 + [1] * 4] * 8,
+                           "masked_lm_labels": [[-100] * 4] * 8,
+                           "ent_masked_lm_labels": [[i] * 4 for i in range(8)], "next_sentence_labels": [0] * 8})
+        neg = pre._add_negative_nsp_samples(df, text_part_length=4)
+        res[f"neg_input_ids_{seed}"] = np.array(neg["input_ids"].tolist())
+        res[f"neg_ent_labels_{seed}"] = np.array(neg["ent_masked_lm_labels"].tolist())
+        res[f"neg_nsp_{seed}"] = np.array(neg["next_sentence_labels"].tolist())
+    np.savez_compressed(os.path.join(OUT, "masking.npz"), **res)
+    print("masking: first positions seed 1234:", [i for i, l in enumerate(res["text_lab_1234"]) if l != -100][:8])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    sm, pre = import_reference()
+    # G1: tiny, every tensor stored (pins the oracle op for op)
+    model_case("g1_tiny", sm, pre, orc.OracleConfig(vocab_size=300, kg_vocab_size=150, hidden_size=64, num_hidden_layers=2,
+                                                   num_attention_heads=4, intermediate_size=128,
+                                                   max_position_embeddings=16), B=3, seed=100, full_logits=True)
+    # G2: smallest shape the HIP path supports (head_dim 64, S = 256 = 128 + 128): pins GPU parity directly
+    model_case("g2_hipsmall", sm, pre, orc.OracleConfig(vocab_size=512, kg_vocab_size=300, hidden_size=128,
+                                                       num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                                                       max_position_embeddings=256), B=3, seed=200, full_logits=False)
+    masking_case(pre)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+"""CPU: the oracle (oracle/stonkgs_oracle.py) against golden vectors produced by the REFERENCE itself
+(oracle/make_golden.py ran the reference's forward + HF BERT + torch AdamW in the authoring container)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stonkgs_oracle as orc
+from tests.golden_util import GOLDEN, load_case
+
+
+@pytest.fixture(scope="module", params=["g1_tiny", "g2_hipsmall"])
+def case(request):
+    return load_case(request.param)
+
+
+def _table(cfg, sd, tsv_rows):
+    return orc.build_kg_table(tsv_rows, orc.special_vectors(sd, cfg))
+
+
+def test_forward_matches_reference(case):
+    cfg, sd, tsv_rows, batch, gold, meta = case
+    with torch.no_grad():
+        table = _table(cfg, sd, tsv_rows)
+        for sid in (100, 102, 103):  # quirk Q2
+            np.testing.assert_allclose(table[sid].numpy(), gold[f"special_{sid}"], rtol=1e-5, atol=2e-6)
+        out = orc.forward(sd, cfg, table, **batch)
+    for k in ("loss", "masked_lm_loss", "ent_masked_lm_loss", "next_sentence_loss"):
+        assert abs(float(out[k]) - float(gold[k])) <= 1e-5, k
+    np.testing.assert_allclose(out["nsp_logits"].numpy(), gold["nsp_logits"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(out["pooler_output"].numpy(), gold["pooler_output"], rtol=1e-5, atol=1e-5)
+    if "text_logits" in gold:
+        np.testing.assert_allclose(out["hidden_states"].numpy(), gold["hidden_states"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out["text_logits"].numpy(), gold["text_logits"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out["ent_logits"].numpy(), gold["ent_logits"], rtol=1e-4, atol=1e-5)
+    else:
+        np.testing.assert_allclose(out["hidden_states"][:, ::7, ::3].numpy(), gold["hidden_states_s"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out["text_logits"][:, ::5, ::3].numpy(), gold["text_logits_s"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(out["ent_logits"][batch["ent_masked_lm_labels"] != -100].numpy(),
+                                   gold["ent_logits_lab"], rtol=1e-4, atol=1e-5)
+
+
+def test_gradients_and_two_optimizer_steps_match_reference(case):
+    cfg, sd, tsv_rows, batch, gold, meta = case
+    with torch.no_grad():
+        table = _table(cfg, sd, tsv_rows)
+    sd = {k: v.clone() for k, v in sd.items()}
+    state = orc.AdamState()
+    r1 = orc.train_step(sd, cfg, table, batch, state, base_lr=1e-4, max_steps=200)
+    assert abs(float(r1["grad_norm"]) - float(gold["grad_norm"])) <= 1e-4 * float(gold["grad_norm"])
+    for k in meta["grad_keys"]:
+        np.testing.assert_allclose(r1["grads"][k].numpy(), gold["grad::" + k], rtol=2e-4, atol=2e-6, err_msg=k)
+    # dead parameters (quirk Q4) never receive a gradient in the reference either
+    assert set(meta["dead_parameters"]).isdisjoint(orc.trainable_names(sd))
+    r2 = orc.train_step(sd, cfg, table, batch, state, base_lr=1e-4, max_steps=200)
+    np.testing.assert_allclose([float(r1["loss"]), float(r2["loss"])], gold["step_losses"], rtol=0, atol=2e-5)
+    for k in meta["grad_keys"]:
+        np.testing.assert_allclose(sd[k].numpy(), gold["after2::" + k], rtol=0, atol=2e-6, err_msg=k)
+
+
+def test_masking_is_bit_exact():
+    gold = dict(np.load(GOLDEN + "/masking.npz"))
+    for seed in (0, 1, 1234):
+        random.seed(seed)
+        t_in, t_lab = orc.replace_mlm_tokens(list(range(1000, 1256)), 28996)
+        e_in, e_lab = orc.replace_mlm_tokens([(7 * i) % 175094 for i in range(256)], 175094)
+        assert t_in == gold[f"text_in_{seed}"].tolist() and t_lab == gold[f"text_lab_{seed}"].tolist()
+        assert e_in == gold[f"ent_in_{seed}"].tolist() and e_lab == gold[f"ent_lab_{seed}"].tolist()
+        assert sum(l != -100 for l in t_lab) == 38  # int(256 * 0.15)
+        random.seed(seed)
+        pairs = orc.negative_nsp_index_pairs(8)
+        rows = [list(range(i * 10, i * 10 + 8)) for i in range(8)]
+        neg_ids = [rows[i][:4] + rows[j][4:] for i, j in pairs]
+        assert neg_ids == gold[f"neg_input_ids_{seed}"].tolist()
+        assert [[j] * 4 for _, j in pairs] == gold[f"neg_ent_labels_{seed}"].tolist()
+        assert gold[f"neg_nsp_{seed}"].tolist() == [1] * len(pairs)
+
+
+def test_entity_index_space_quirk_q1():
+    K = 175094
+    exp = {0: 0, 99: 99, 100: None, 101: 100, 102: None, 103: None, 104: 101, K - 1: K - 4, K + 2: K - 1}
+    for e, r in exp.items():
+        assert orc.kg_row_of_entity_id(e) == r
+    sv = {s: torch.full((2,), -float(s)) for s in (100, 102, 103)}
+    big = torch.arange(200, dtype=torch.float64)[:, None].repeat(1, 2)
+    t = orc.build_kg_table(big, sv)
+    assert t.shape[0] == 203 and t[99, 0] == 99 and t[100, 0] == -100 and t[101, 0] == 100 and t[104, 0] == 101
+    assert t[202, 0] == 199
+
+
+def test_out_of_table_entity_raises_keyerror(case):
+    cfg, sd, tsv_rows, batch, gold, meta = case
+    with torch.no_grad():
+        table = _table(cfg, sd, tsv_rows)
+        bad = {k: v.clone() for k, v in batch.items()}
+        bad["input_ids"][0, -1] = cfg.kg_vocab_size + 3
+        with pytest.raises(KeyError):
+            orc.forward(sd, cfg, table, **bad)

@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""Benchmark of the STonKGs pre-training hot path on MI355X (BASELINE.json metric: text-triple pairs/sec, whole node).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one full training step of STonKGsForPreTraining on one synthetic batch per GPU (BASELINE config 2:
+12L/768h, V=28 996, K=175 094, per-GPU batch 64, seq 256 text + 256 entity, dropout 0.1 live incl. the frozen
+backbone, bf16 MFMA compute / fp32 master weights): frozen backbone forward, KG gather, encoder forward, heads,
+3 x cross-entropy, full backward, gradient all-reduce (N > 1), global-norm clip, AdamW, weight refresh.
+Inputs are resident in HBM before the timed region. Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
+# algorithmic GFLOP per text-triple pair, 12L/768/S=512, label-sparse decoders
+GFLOP_PER_PAIR_STEP = 373.4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE config 2: 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference's HuggingFace path, pinned by tests/test_oracle_golden.py) timed
+    on this host's cores: full training steps at the SAME model shape on a bounded sample (B = 2)."""
+    from oracle import stonkgs_oracle as orc
+    from stonkgs_amd.data import synthetic_batch
+
+    ocfg = orc.OracleConfig(vocab_size=cfg.vocab_size, kg_vocab_size=cfg.kg_vocab_size, hidden_size=cfg.hidden_size,
+                            num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                            intermediate_size=cfg.intermediate_size, max_position_embeddings=cfg.max_position_embeddings)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = orc.init_state_dict(ocfg, seed=0, bf16_exact=False)
+    table = torch.randn(ocfg.kg_vocab_size + 3, ocfg.hidden_size) * 0.3
+    B = 2
+    batch = synthetic_batch(B, ocfg.vocab_size, ocfg.kg_vocab_size, ocfg.max_position_embeddings, seed=4321)
+    state = orc.AdamState()
+    orc.train_step(sd, ocfg, table, batch, state)  # warm-up (allocations, oneDNN primitive caches)
+    n, t0 = 0, time.time()
+    while n < 2 or (time.time() - t0 < seconds_budget and n < 8):
+        orc.train_step(sd, ocfg, table, batch, state)
+        n += 1
+    dt = time.time() - t0
+    return {"value": B * n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full fp32 training steps of the CPU oracle at the same model shape, batch {B} "
+                      f"(seq 512, V={ocfg.vocab_size}, K={ocfg.kg_vocab_size}), torch {torch.__version__}"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from stonkgs_amd.config import STonKGsConfig
+    from stonkgs_amd.data import synthetic_batch
+    from stonkgs_amd.stonkgs_model import STonKGsForPreTraining
+    from stonkgs_amd.stonkgs_pretraining import Trainer, TrainingArguments
+
+    cfg = STonKGsConfig()  # 12L / 768h / 12 heads / 3072 / 512 positions / V 28996 / K 175094, dropout 0.1
+    model = STonKGsForPreTraining(cfg, seed=0)  # same seed on every rank: replicas start identical (as DDP broadcasts)
+    trainer = Trainer(model, TrainingArguments(per_device_train_batch_size=args.batch, max_steps=200, learning_rate=1e-4))
+    dev = model.device
+    batches = [{k: v.to(dev) for k, v in synthetic_batch(args.batch, cfg.vocab_size, cfg.kg_vocab_size,
+                                                         cfg.max_position_embeddings, seed=1234 + rank * 100 + i).items()}
+               for i in range(4)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for i in range(args.warmup):
+        loss = trainer.training_step(model, batches[i % len(batches)])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.training_step(model, batches[i % len(batches)])
+    barrier()
+    dt = time.perf_counter() - t0
+    model.engine.check_errors()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss)
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        # dominant kernel = gemm_nt_kernel (every projection / FFN / decoder / wgrad launch): per-launch HIP events on
+        # the launch stream over two extra steps; achieved = algorithmic FLOPs of those launches / their duration
+        from stonkgs_amd.engine import GemmTimer
+
+        model.engine.gemm_timer = GemmTimer()
+        for i in range(2):
+            trainer.training_step(model, batches[i % len(batches)])
+        s = model.engine.gemm_timer.summarize()
+        model.engine.gemm_timer = None
+        ach = s["flops"] / s["seconds"] / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32, 128x128x64 tiles)",
+                    "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": s["launches"] // 2,
+                    "avg_launch_us": round(s["seconds"] / s["launches"] * 1e6, 1),
+                    "avg_launch_gflop": round(s["flops"] / s["launches"] / 1e9, 2)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        pairs = args.batch * world * args.steps
+        value = pairs / dt
+        out = {"metric": "text-triple pairs/sec (whole node), seq_len=512 hidden=768", "value": round(value, 2),
+               "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "STonKGs-150k pretraining step (12L/768h, V=28996, K=175094), per-GPU batch "
+                                      f"{args.batch}, seq 256 text + 256 entity, dropout 0.1, AdamW lr 1e-4",
+                          "global_batch": args.batch * world, "seq_len": 512, "parallelism": f"dp{world}"},
+               "final_loss": round(final_loss, 4),
+               "step_mfma_frac": round(value * GFLOP_PER_PAIR_STEP / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

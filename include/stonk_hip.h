@@ -124,6 +124,9 @@ int stonk_small_linear_bwd(const float* dy, const float* y, const void* x, int64
                            float* db, float* dx_f32, void* dx_bf16_accum, int64_t ld_dxb, int M, int N, int K, int act,
                            void* stream);
 
+/* du = dg * gelu'(u), bf16 elementwise (backward of hf:modeling_bert.py:478, the head transform's activation). */
+int stonk_gelu_bwd_bf16(const void* dg, const void* u, void* du, int64_t n, void* stream);
+
 /* Optimizer step pieces (hf:trainer.py:1780-1796 as driven by ref:src/stonkgs/models/stonkgs_pretraining.py:171-223):
  * *out_accum += sum(x^2); fused clip_grad_norm_(max_grad_norm) + AdamW + bf16 weight refresh + grad zeroing. */
 int stonk_sumsq_f32(const float* x, int64_t n, float* out_accum, void* stream);

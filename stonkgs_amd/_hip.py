@@ -55,6 +55,7 @@ _SIGNATURES = {
     "stonk_loss_finalize": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "stonk_small_linear_fwd": [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "stonk_small_linear_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
+    "stonk_gelu_bwd_bf16": [_vp, _vp, _vp, _i64, _vp],
     "stonk_sumsq_f32": [_vp, _i64, _vp, _vp],
     "stonk_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _f32, _f32,
                          _vp],
@@ -78,6 +79,10 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()). "
                 "There is no CPU fallback for the STonKGs hot path."
             )
+        # torch bundles its own libamdhip64 (same soname as /opt/rocm's): import it FIRST so that this library
+        # binds to the HIP runtime torch already initialised - one runtime per process, shared streams
+        import torch  # noqa: F401
+
         handle = C.CDLL(LIB_PATH)
         missing = [name for name in _SIGNATURES if not hasattr(handle, name)]
         if missing and os.environ.get("STONK_DEV_PARTIAL") == "1":  # kernel bring-up only

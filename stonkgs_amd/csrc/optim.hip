@@ -100,65 +100,68 @@ __global__ __launch_bounds__(256) void transpose_kernel(const SrcT* __restrict__
   if (rows_dev) {
     const long rd = *rows_dev;
     live = rd < rows ? rd : rows;
-    // tiles entirely past the 64-row round-up of the live count are never consumed
-    if ((long)blockIdx.y * TT >= ((live + TT - 1) / TT) * TT) return;
   }
+  // only tiles up to the 64-row round-up of the live count are ever consumed; blocks walk them with stride gridDim.y
+  const long live_tiles = (live + TT - 1) / TT;
   const int t = threadIdx.x;
-  const long r0 = (long)blockIdx.y * TT;
   const int c0 = blockIdx.x * TT;
-  // load: thread -> (row = t >> 3 (+32), 8 columns)
+  for (long rt = blockIdx.y; rt < live_tiles; rt += gridDim.y) {
+    const long r0 = rt * TT;
+    // load: thread -> (row = t >> 3 (+32), 8 columns)
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int rr = (t >> 3) + 32 * pass;
-    const int cc = (t & 7) * 8;
-    const long r = r0 + rr;
-    unsigned short vals[8];
-    if (r < live && c0 + cc < cols) {
-      if constexpr (sizeof(SrcT) == 2) {
-        const u16x8 v = *(const u16x8*)(in + r * ld_in + c0 + cc);
+    for (int pass = 0; pass < 2; ++pass) {
+      const int rr = (t >> 3) + 32 * pass;
+      const int cc = (t & 7) * 8;
+      const long r = r0 + rr;
+      unsigned short vals[8];
+      if (r < live && c0 + cc < cols) {
+        if constexpr (sizeof(SrcT) == 2) {
+          const u16x8 v = *(const u16x8*)(in + r * ld_in + c0 + cc);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vals[j] = v[j];
-      } else {
-        const f32x4 a = *(const f32x4*)(in + r * ld_in + c0 + cc);
-        const f32x4 b = *(const f32x4*)(in + r * ld_in + c0 + cc + 4);
+          for (int j = 0; j < 8; ++j) vals[j] = v[j];
+        } else {
+          const f32x4 a = *(const f32x4*)(in + r * ld_in + c0 + cc);
+          const f32x4 b = *(const f32x4*)(in + r * ld_in + c0 + cc + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          vals[j] = bf16_bits(a[j]);
-          vals[4 + j] = bf16_bits(b[j]);
+          for (int j = 0; j < 4; ++j) {
+            vals[j] = bf16_bits(a[j]);
+            vals[4 + j] = bf16_bits(b[j]);
+          }
         }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vals[j] = 0;
       }
-    } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) vals[j] = 0;
+      for (int j = 0; j < 8; ++j) tile[rr][cc + j] = vals[j];
     }
+    __syncthreads();
+    // store: thread -> (out row = column c0 + (t >> 2), 16 source rows = 32 contiguous bytes)
+    {
+      const int oc = t >> 2;
+      const int rb = (t & 3) * 16;
+      if (c0 + oc < cols) {
+        unsigned short vals[16];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) tile[rr][cc + j] = vals[j];
-  }
-  __syncthreads();
-  // store: thread -> (out row = column c0 + (t >> 2), 16 source rows = 32 contiguous bytes)
-  {
-    const int oc = t >> 2;
-    const int rb = (t & 3) * 16;
-    if (c0 + oc < cols) {
-      unsigned short vals[16];
+        for (int j = 0; j < 16; ++j) vals[j] = tile[rb + j][oc];
+        bf16* dst = out + (long)(c0 + oc) * ld_out + r0 + rb;
+        u16x8 o0, o1;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) vals[j] = tile[rb + j][oc];
-      bf16* dst = out + (long)(c0 + oc) * ld_out + r0 + rb;
-      u16x8 o0, o1;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        o0[j] = vals[j];
-        o1[j] = vals[8 + j];
+        for (int j = 0; j < 8; ++j) {
+          o0[j] = vals[j];
+          o1[j] = vals[8 + j];
+        }
+        *(u16x8*)dst = o0;
+        *(u16x8*)(dst + 8) = o1;
       }
-      *(u16x8*)dst = o0;
-      *(u16x8*)(dst + 8) = o1;
     }
-  }
-  if (colsum && t < TT && c0 + t < cols) {
-    float s = 0.f;
+    if (colsum && t < TT && c0 + t < cols) {
+      float s = 0.f;
 #pragma unroll 8
-    for (int r = 0; r < TT; ++r) s += bits_to_float(tile[r][t]);
-    atomicAdd(colsum + c0 + t, s);
+      for (int r = 0; r < TT; ++r) s += bits_to_float(tile[r][t]);
+      atomicAdd(colsum + c0 + t, s);
+    }
+    __syncthreads();
   }
 }
 
@@ -214,7 +217,10 @@ extern "C" int stonk_transpose_bf16(const void* in, int64_t ld_in, void* out, in
   STONK_CHECK_ARG(cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0, STONK_EALIGN);
   STONK_CHECK_ARG(ld_out >= ((rows + TT - 1) / TT) * TT, STONK_ESHAPE);
   if (rows == 0) return STONK_OK;
-  const dim3 grid((cols + TT - 1) / TT, (unsigned)((rows + TT - 1) / TT));
+  long rtiles = (rows + TT - 1) / TT;
+  if (rows_dev && rtiles > 64) rtiles = 64;  // live count unknown on the host: bounded grid, blocks stride
+  if (rtiles > 65535) rtiles = 65535;
+  const dim3 grid((cols + TT - 1) / TT, (unsigned)rtiles);
   hipLaunchKernelGGL((transpose_kernel<bf16>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)in, (long)ld_in,
                      (bf16*)out, (long)ld_out, (long)rows, cols, colsum, rows_dev);
   return stonk_launch_status();
@@ -227,7 +233,9 @@ extern "C" int stonk_transpose_f32_to_bf16(const float* in, void* out, int64_t r
   STONK_CHECK_ARG(cols % 8 == 0 && ld_out % 8 == 0, STONK_EALIGN);
   STONK_CHECK_ARG(ld_out >= ((rows + TT - 1) / TT) * TT, STONK_ESHAPE);
   if (rows == 0) return STONK_OK;
-  const dim3 grid((cols + TT - 1) / TT, (unsigned)((rows + TT - 1) / TT));
+  long rtiles = (rows + TT - 1) / TT;
+  if (rtiles > 65535) rtiles = 65535;
+  const dim3 grid((cols + TT - 1) / TT, (unsigned)rtiles);
   hipLaunchKernelGGL((transpose_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, in, (long)cols, (bf16*)out,
                      (long)ld_out, (long)rows, cols, (float*)nullptr, (const int*)nullptr);
   return stonk_launch_status();

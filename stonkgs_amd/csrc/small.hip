@@ -115,3 +115,28 @@ extern "C" int stonk_small_linear_bwd(const float* dy, const float* y, const voi
   }
   return stonk_launch_status();
 }
+
+// du = dg * gelu'(u)  (bf16, elementwise): backward of the GELU inside BertPredictionHeadTransform
+// (hf:models/bert/modeling_bert.py:476-480), where no GEMM epilogue is available to carry it.
+namespace {
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ dg, const bf16* __restrict__ u,
+                                                       bf16* __restrict__ du, long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const bf16x8 a = *(const bf16x8*)(dg + 8 * i), b = *(const bf16x8*)(u + 8 * i);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)a[j] * gelu_erf_grad((float)b[j]));
+    *(bf16x8*)(du + 8 * i) = o;
+  }
+}
+}  // namespace
+
+extern "C" int stonk_gelu_bwd_bf16(const void* dg, const void* u, void* du, int64_t n, void* stream) {
+  STONK_CHECK_ARG(dg && u && du && n >= 0 && n % 8 == 0, STONK_EINVAL);
+  if (n == 0) return STONK_OK;
+  const long n8 = n / 8;
+  const long g = (n8 + 255) / 256;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)(g < 4096 ? g : 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)dg, (const bf16*)u, (bf16*)du, n8);
+  return stonk_launch_status();
+}

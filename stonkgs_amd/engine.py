@@ -1,0 +1,453 @@
+"""HIP execution engine for the STonKGs hot path: schedules the C-ABI kernels (include/stonk_hip.h) for
+forward, backward and the derived-weight refresh.  No torch arithmetic on the data path: torch tensors are
+device memory, ``torch.cuda.current_stream()`` is the stream every launcher is given.
+
+Call structure mirrors SURVEY.md section 3.2 (ref:src/stonkgs/models/stonkgs_model.py:149-258):
+  F1 frozen LM backbone on the text half  ->  F2 KG gather + concat + embeddings LayerNorm  ->  F3 encoder layers
+  ->  F4 pooler / NSP  ->  F5 head transform  ->  F6 label-sparse decoders + fused cross-entropy
+and the mirrored backward.  Activations needed by backward are kept in a persistent workspace (HBM is 288 GB;
+B=64 needs ~12 GB), nothing is recomputed except attention probabilities.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import _hip as hip
+from .config import STonKGsConfig
+from .params import FlatStore, pad128
+
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+
+ERR_BITS = {1: "entity id outside the KG table (the reference raises KeyError, stonkgs_model.py:185)",
+            2: "token_type_id outside [0, type_vocab_size)", 4: "text token id outside the LM vocabulary",
+            8: "MLM/ELM label outside the decoder's class range", 16: "NSP label outside [0, 2)"}
+
+
+class GemmTimer:
+    """Optional per-launch HIP-event timing of the GEMM kernel (bench.py roofline leg)."""
+
+    def __init__(self):
+        self.records = []  # (start_event, end_event, flops)
+
+    def summarize(self):
+        torch.cuda.synchronize()
+        tot_t = sum(s.elapsed_time(e) for s, e, _ in self.records) * 1e-3
+        tot_f = sum(f for _, _, f in self.records)
+        return {"launches": len(self.records), "seconds": tot_t, "flops": tot_f}
+
+
+class Engine:
+    def __init__(self, cfg: STonKGsConfig, store: FlatStore, backbone: FlatStore, n_backbone_layers: int, device):
+        cfg.validate_for_hip()
+        hip.lib()  # fail loudly, now, if the extension is missing
+        self.cfg = cfg
+        self.P = store
+        self.BB = backbone
+        self.n_bb = n_backbone_layers
+        self.device = device
+        self.ws: Dict[str, torch.Tensor] = {}
+        self.kg_table: Optional[torch.Tensor] = None  # fp32 [K+3, H]
+        self.err = torch.zeros(1, dtype=I32, device=device)
+        self.gemm_timer: Optional[GemmTimer] = None
+        self.saved = None
+        self.seed_base = 0x5710
+
+    # ------------------------------------------------------------------ plumbing
+    def buf(self, name: str, shape, dtype=BF16, zero=False) -> torch.Tensor:
+        n = 1
+        for d in shape:
+            n *= d
+        t = self.ws.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(max(n, 1), dtype=dtype, device=self.device)
+            self.ws[name] = t
+        return t[:n].view(shape)
+
+    def check_errors(self) -> None:
+        """Raise for any flag the kernels set (one tiny D2H copy; call where a sync is acceptable)."""
+        e = int(self.err.item())
+        if e:
+            self.err.zero_()
+            msgs = [m for b, m in ERR_BITS.items() if e & b]
+            if e & 1:
+                raise KeyError("; ".join(msgs))
+            raise IndexError("; ".join(msgs))
+
+    def gemm(self, A, B, C, M, N, K, flags=0, bias=None, resid=None, aux=None, alpha=1.0, split_k=1, m_dev=None,
+             k_dev=None, drop_p=0.0, seed=0):
+        st = hip.stream_ptr()
+        timed = self.gemm_timer is not None
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        hip.call("stonk_gemm_nt_bf16", A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), C.stride(0),
+                 M, N, K, flags, hip.ptr(bias), hip.ptr(resid), 0 if resid is None else resid.stride(0), hip.ptr(aux),
+                 0 if aux is None else aux.stride(0), alpha, split_k, hip.ptr(m_dev), hip.ptr(k_dev), drop_p,
+                 seed & 0xFFFFFFFF, st)
+        if timed:
+            e1.record()
+            self.gemm_timer.records.append((e0, e1, 2.0 * M * N * K))
+
+    @staticmethod
+    def _split_k(M, N, K) -> int:
+        tiles = ((M + 127) // 128) * (N // 128)
+        s = max(1, min(16, (640 + tiles - 1) // tiles, K // 64))
+        return s
+
+    def wgrad(self, dyT, xT, dW, M_out, N_in, K, k_dev=None, alpha=1.0):
+        """dW[M_out, N_in] += dyT[M_out, K] . xT[N_in, K]^T   (fp32 atomics, split-K)."""
+        self.gemm(dyT, xT, dW, M_out, N_in, K, flags=hip.EPI_OUT_F32_ATOMIC, split_k=self._split_k(M_out, N_in, K),
+                  k_dev=k_dev, alpha=alpha)
+
+    def transpose(self, x, rows, cols, name, colsum=None, rows_dev=None):
+        rpad = (rows + 63) // 64 * 64
+        out = self.buf(name, (cols, rpad))
+        hip.call("stonk_transpose_bf16", x.data_ptr(), x.stride(0), out.data_ptr(), rpad, rows, cols, hip.ptr(colsum),
+                 hip.ptr(rows_dev), hip.stream_ptr())
+        return out
+
+    def seed(self, layer: int, site: int) -> int:
+        return (self.seed_base * 0x9E3779B1 + layer * 64 + site) & 0xFFFFFFFF
+
+    # ------------------------------------------------------------------ derived weights
+    def refresh_derived(self, bf16_mirror: bool = True) -> None:
+        """bf16 mirrors (if the optimizer has not just written them) and W^T copies for dgrad."""
+        st = hip.stream_ptr()
+        if bf16_mirror:
+            for s in (self.P, self.BB):
+                hip.call("stonk_cast_f32_to_bf16", s.data.data_ptr(), s.bf16.data_ptr(), s.numel, st)
+        H = self.cfg.hidden_size
+        for name, (off, shape, pshape) in self.P.index.items():
+            if len(shape) != 2 or not name.endswith(".weight") or shape[0] < 64:
+                continue
+            if "embeddings" in name or "pooler" in name or "seq_relationship" in name:
+                continue
+            rows, cols = shape
+            rpad = pshape[0] if pshape[0] % 64 == 0 else (pshape[0] + 63) // 64 * 64
+            wt = self.P.wt.get(name)
+            if wt is None:
+                wt = torch.zeros(cols, rpad, dtype=BF16, device=self.device)
+                self.P.wt[name] = wt
+            hip.call("stonk_transpose_f32_to_bf16", self.P.view(name).data_ptr(), wt.data_ptr(), rows, cols, rpad, st)
+
+    # ------------------------------------------------------------------ one BERT layer
+    def layer_fwd(self, S: FlatStore, prefix: str, x, B, seq, mask, p_hid, p_att, lidx, save: Optional[dict]):
+        cfg = self.cfg
+        H, I, NH = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
+        T = B * seq
+        st = hip.stream_ptr()
+        tag = prefix if save is not None else "tmp"
+        w = S.bf16_view
+        f = S.view
+        qkv = self.buf(f"{tag}.qkv", (T, 3 * H))
+        self.gemm(x, w(prefix + ".attention.self.qkv.weight"), qkv, T, 3 * H, H, flags=hip.EPI_BIAS,
+                  bias=f(prefix + ".attention.self.qkv.bias"))
+        ctx = self.buf(f"{tag}.ctx", (T, H))
+        lse = self.buf(f"{tag}.lse", (B, NH, seq), F32)
+        hip.call("stonk_attention_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H,
+                 hip.ptr(mask), ctx.data_ptr(), H, lse.data_ptr(), B, NH, seq, 64, 1.0 / math.sqrt(64.0), p_att,
+                 self.seed(lidx, 1), st)
+        s1 = self.buf(f"{tag}.s1", (T, H))
+        fl = hip.EPI_BIAS | hip.EPI_RESID | (hip.EPI_DROPOUT if p_hid > 0 else 0)
+        self.gemm(ctx, w(prefix + ".attention.output.dense.weight"), s1, T, H, H, flags=fl,
+                  bias=f(prefix + ".attention.output.dense.bias"), resid=x, drop_p=p_hid, seed=self.seed(lidx, 2))
+        h1 = self.buf(f"{tag}.h1", (T, H))
+        st1 = self.buf(f"{tag}.st1", (2, T), F32)
+        hip.call("stonk_layernorm_fwd", s1.data_ptr(), f(prefix + ".attention.output.LayerNorm.weight").data_ptr(),
+                 f(prefix + ".attention.output.LayerNorm.bias").data_ptr(), h1.data_ptr(), st1[0].data_ptr(),
+                 st1[1].data_ptr(), T, H, cfg.layer_norm_eps, 0, 0.0, 0, st)
+        g = self.buf(f"{tag}.g", (T, I))
+        u = self.buf(f"{tag}.u", (T, I)) if save is not None else None
+        fl = hip.EPI_BIAS | hip.EPI_GELU | (hip.EPI_SAVE_PREACT if save is not None else 0)
+        self.gemm(h1, w(prefix + ".intermediate.dense.weight"), g, T, I, H, flags=fl,
+                  bias=f(prefix + ".intermediate.dense.bias"), aux=u)
+        s2 = self.buf(f"{tag}.s2", (T, H))
+        fl = hip.EPI_BIAS | hip.EPI_RESID | (hip.EPI_DROPOUT if p_hid > 0 else 0)
+        self.gemm(g, w(prefix + ".output.dense.weight"), s2, T, H, I, flags=fl, bias=f(prefix + ".output.dense.bias"),
+                  resid=h1, drop_p=p_hid, seed=self.seed(lidx, 3))
+        y = self.buf(f"{prefix}.y" if save is not None else f"tmp.y{lidx & 1}", (T, H))
+        st2 = self.buf(f"{tag}.st2", (2, T), F32)
+        hip.call("stonk_layernorm_fwd", s2.data_ptr(), f(prefix + ".output.LayerNorm.weight").data_ptr(),
+                 f(prefix + ".output.LayerNorm.bias").data_ptr(), y.data_ptr(), st2[0].data_ptr(), st2[1].data_ptr(), T,
+                 H, cfg.layer_norm_eps, 0, 0.0, 0, st)
+        if save is not None:
+            save[prefix] = dict(x=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, h1=h1, st1=st1, g=g, u=u, s2=s2, st2=st2)
+        return y
+
+    def layer_bwd(self, prefix: str, dy, B, seq, mask, p_hid, p_att, lidx, sv):
+        """dy: bf16 [T,H] gradient of the layer output. Returns the gradient of the layer input."""
+        cfg = self.cfg
+        H, I, NH = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
+        T = B * seq
+        st = hip.stream_ptr()
+        P = self.P
+        g_ = P.grad_view
+        f = P.view
+        wt = P.wt
+        # ---- LN2 backward: ds2 (residual branch) and df (through the FFN-output dropout)
+        ds2 = self.buf("b.ds2", (T, H))
+        df = self.buf("b.df", (T, H)) if p_hid > 0 else None
+        hip.call("stonk_layernorm_bwd", dy.data_ptr(), sv["s2"].data_ptr(), sv["st2"][0].data_ptr(),
+                 sv["st2"][1].data_ptr(), f(prefix + ".output.LayerNorm.weight").data_ptr(), ds2.data_ptr(), hip.ptr(df),
+                 g_(prefix + ".output.LayerNorm.weight").data_ptr(), g_(prefix + ".output.LayerNorm.bias").data_ptr(),
+                 T, H, 0, 0.0, 0, p_hid, self.seed(lidx, 3), st)
+        if df is None:
+            df = ds2
+        # ---- FFN down: wgrad, bias grad, dgrad fused with GELU'
+        dfT = self.transpose(df, T, H, "b.tA_H", colsum=g_(prefix + ".output.dense.bias"))
+        gT = self.transpose(sv["g"], T, I, "b.tB_I")
+        self.wgrad(dfT, gT, g_(prefix + ".output.dense.weight"), H, I, T)
+        du = self.buf("b.du", (T, I))
+        self.gemm(df, wt[prefix + ".output.dense.weight"], du, T, I, H, flags=hip.EPI_GELU_BWD, aux=sv["u"])
+        # ---- FFN up
+        duT = self.transpose(du, T, I, "b.tA_I", colsum=g_(prefix + ".intermediate.dense.bias"))
+        h1T = self.transpose(sv["h1"], T, H, "b.tB_H")
+        self.wgrad(duT, h1T, g_(prefix + ".intermediate.dense.weight"), I, H, T)
+        dh1 = self.buf("b.dh1", (T, H))
+        self.gemm(du, wt[prefix + ".intermediate.dense.weight"], dh1, T, H, I, flags=hip.EPI_RESID, resid=ds2)
+        # ---- LN1 backward
+        ds1 = self.buf("b.ds1", (T, H))
+        da = self.buf("b.da", (T, H)) if p_hid > 0 else None
+        hip.call("stonk_layernorm_bwd", dh1.data_ptr(), sv["s1"].data_ptr(), sv["st1"][0].data_ptr(),
+                 sv["st1"][1].data_ptr(), f(prefix + ".attention.output.LayerNorm.weight").data_ptr(), ds1.data_ptr(),
+                 hip.ptr(da), g_(prefix + ".attention.output.LayerNorm.weight").data_ptr(),
+                 g_(prefix + ".attention.output.LayerNorm.bias").data_ptr(), T, H, 0, 0.0, 0, p_hid, self.seed(lidx, 2),
+                 st)
+        if da is None:
+            da = ds1
+        # ---- attention output projection
+        daT = self.transpose(da, T, H, "b.tA_H", colsum=g_(prefix + ".attention.output.dense.bias"))
+        ctxT = self.transpose(sv["ctx"], T, H, "b.tB_H")
+        self.wgrad(daT, ctxT, g_(prefix + ".attention.output.dense.weight"), H, H, T)
+        dctx = self.buf("b.dctx", (T, H))
+        self.gemm(da, wt[prefix + ".attention.output.dense.weight"], dctx, T, H, H)
+        # ---- attention core
+        qkv = sv["qkv"]
+        dqkv = self.buf("b.dqkv", (T, 3 * H))
+        delta = self.buf("b.delta", (B, NH, seq), F32)
+        hip.call("stonk_attention_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H,
+                 hip.ptr(mask), sv["ctx"].data_ptr(), H, dctx.data_ptr(), H, sv["lse"].data_ptr(), delta.data_ptr(),
+                 dqkv.data_ptr(), dqkv.data_ptr() + 2 * H, 3 * H, dqkv.data_ptr() + 4 * H, B, NH, seq, 64,
+                 1.0 / math.sqrt(64.0), p_att, self.seed(lidx, 1), st)
+        # ---- QKV projection
+        dqkvT = self.transpose(dqkv, T, 3 * H, "b.tA_3H", colsum=g_(prefix + ".attention.self.qkv.bias"))
+        xT = self.transpose(sv["x"], T, H, "b.tB_H")
+        self.wgrad(dqkvT, xT, g_(prefix + ".attention.self.qkv.weight"), 3 * H, H, T)
+        dx = self.buf(f"b.dx{lidx & 1}", (T, H))
+        self.gemm(dqkv, wt[prefix + ".attention.self.qkv.weight"], dx, T, H, 3 * H, flags=hip.EPI_RESID, resid=ds1)
+        return dx
+
+    # ------------------------------------------------------------------ frozen backbone
+    def backbone_fwd(self, input_ids, ld_ids, B, seq, training: bool, mask=None):
+        cfg = self.cfg
+        H = cfg.hidden_size
+        p_hid = cfg.hidden_dropout_prob if training else 0.0  # quirk Q6: dropout is live inside the frozen LM
+        p_att = cfg.attention_probs_dropout_prob if training else 0.0
+        f = self.BB.view
+        x = self.buf("bb.x", (B * seq, H))
+        hip.call("stonk_text_embed_ln_fwd", input_ids.data_ptr(), ld_ids,
+                 f("lm_backbone.embeddings.word_embeddings.weight").data_ptr(),
+                 f("lm_backbone.embeddings.position_embeddings.weight").data_ptr(),
+                 f("lm_backbone.embeddings.token_type_embeddings.weight").data_ptr(),
+                 f("lm_backbone.embeddings.LayerNorm.weight").data_ptr(),
+                 f("lm_backbone.embeddings.LayerNorm.bias").data_ptr(), x.data_ptr(), B, seq, H, cfg.vocab_size,
+                 cfg.layer_norm_eps, hip.LN_DROPOUT if p_hid > 0 else 0, p_hid, self.seed(100, 0), self.err.data_ptr(),
+                 hip.stream_ptr())
+        for i in range(self.n_bb):
+            x = self.layer_fwd(self.BB, f"lm_backbone.encoder.layer.{i}", x, B, seq, mask, p_hid, p_att, 101 + i, None)
+        return x
+
+    def special_vectors(self) -> Dict[int, torch.Tensor]:
+        """Quirk Q2: kg_backbone[sid] = lm_backbone([[sid]])[0][0][0], eval mode. A 1-token sequence is run as a
+        128-token sequence whose only unmasked key is position 0 - identical arithmetic for that position."""
+        ids = torch.zeros(3, 128, dtype=torch.long, device=self.device)
+        ids[:, 0] = torch.tensor([102, 103, 100], device=self.device)
+        mask = torch.zeros(3, 128, dtype=torch.long, device=self.device)
+        mask[:, 0] = 1
+        out = self.backbone_fwd(ids, 128, 3, 128, False, mask=mask).view(3, 128, -1)[:, 0].float()
+        return {102: out[0].clone(), 103: out[1].clone(), 100: out[2].clone()}
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_ids, attention_mask, token_type_ids, mlm_labels, ent_labels, nsp_labels, training: bool,
+                dense_logits: bool, need_backward: bool):
+        cfg = self.cfg
+        H, S, half = cfg.hidden_size, cfg.max_position_embeddings, cfg.half_length
+        B = input_ids.shape[0]
+        T = B * S
+        st = hip.stream_ptr()
+        P = self.P
+        f, w = P.view, P.bf16_view
+        self.seed_base += 1
+        p_hid = cfg.hidden_dropout_prob if training else 0.0
+        p_att = cfg.attention_probs_dropout_prob if training else 0.0
+        save: dict = {}
+        # F1 frozen backbone (no attention mask: quirk Q5)
+        text_hidden = self.backbone_fwd(input_ids, S, B, half, training)
+        # F2 gather + concat + embeddings LayerNorm
+        sum0 = self.buf("e.sum0", (T, H))
+        x = self.buf("e.x0", (T, H))
+        st0 = self.buf("e.st0", (2, T), F32)
+        hip.call("stonk_joint_embed_ln_fwd", input_ids.data_ptr(), hip.ptr(token_type_ids), text_hidden.data_ptr(),
+                 self.kg_table.data_ptr(), f("bert.embeddings.position_embeddings.weight").data_ptr(),
+                 f("bert.embeddings.token_type_embeddings.weight").data_ptr(),
+                 f("bert.embeddings.LayerNorm.weight").data_ptr(), f("bert.embeddings.LayerNorm.bias").data_ptr(),
+                 sum0.data_ptr(), x.data_ptr(), st0[0].data_ptr(), st0[1].data_ptr(), B, S, half, H,
+                 self.kg_table.shape[0], cfg.type_vocab_size, cfg.layer_norm_eps, hip.LN_DROPOUT if p_hid > 0 else 0,
+                 p_hid, self.seed(200, 0), self.err.data_ptr(), st)
+        # F3 encoder
+        for i in range(cfg.num_hidden_layers):
+            x = self.layer_fwd(P, f"bert.encoder.layer.{i}", x, B, S, attention_mask, p_hid, p_att, i, save)
+        seq_out = x
+        # F4 pooler + NSP (fp32 master weights)
+        pooled = self.buf("h.pooled", (B, H), F32)
+        hip.call("stonk_small_linear_fwd", seq_out.data_ptr(), S * H, f("bert.pooler.dense.weight").data_ptr(),
+                 f("bert.pooler.dense.bias").data_ptr(), pooled.data_ptr(), B, H, H, hip.SMALL_TANH, st)
+        nsp = self.buf("h.nsp", (B, 2), F32)
+        hip.call("stonk_small_linear_fwd", pooled.data_ptr(), H, f("cls.seq_relationship.weight").data_ptr(),
+                 f("cls.seq_relationship.bias").data_ptr(), nsp.data_ptr(), B, 2, H, hip.SMALL_X_F32, st)
+        # F5 head transform: dense + GELU, LayerNorm
+        gt = self.buf("h.gt", (T, H))
+        ut = self.buf("h.ut", (T, H))
+        self.gemm(seq_out, w("cls.predictions.transform.dense.weight"), gt, T, H, H,
+                  flags=hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT,
+                  bias=f("cls.predictions.transform.dense.bias"), aux=ut)
+        t = self.buf("h.t", (T, H))
+        stt = self.buf("h.stt", (2, T), F32)
+        hip.call("stonk_layernorm_fwd", gt.data_ptr(), f("cls.predictions.transform.LayerNorm.weight").data_ptr(),
+                 f("cls.predictions.transform.LayerNorm.bias").data_ptr(), t.data_ptr(), stt[0].data_ptr(),
+                 stt[1].data_ptr(), T, H, cfg.layer_norm_eps, 0, 0.0, 0, st)
+        out = dict(hidden_states=seq_out.view(B, S, H), pooler_output=pooled, nsp_logits=nsp)
+        heads = (("text", "cls.predictions.text_decoder.weight", cfg.vocab_size, 0, mlm_labels),
+                 ("ent", "cls.predictions.entity_decoder.weight", cfg.kg_vocab_size, half, ent_labels))
+        have_labels = mlm_labels is not None and ent_labels is not None and nsp_labels is not None
+        # F6 label-sparse decoders + fused softmax cross-entropy (value and logits-gradient in one sweep)
+        if have_labels:
+            acc = self.buf("l.acc", (8,), F32)  # [text_sum, ent_sum, nsp_sum, nsp_cnt, loss x4]
+            acc.zero_()
+            cnts = self.buf("l.cnt", (2,), I32)
+            cap = B * half
+            for hi, (nm, wname, N, off, labels) in enumerate(heads):
+                npad = pad128(N)
+                rows = self.buf(f"l.{nm}.rows", (cap,), I32)
+                tg = self.buf(f"l.{nm}.tg", (cap,), I32)
+                cnt = cnts[hi:hi + 1]
+                hip.call("stonk_label_compact", labels.data_ptr(), cap, half, S, off, rows.data_ptr(), tg.data_ptr(),
+                         cnt.data_ptr(), st)
+                hs = self.buf(f"l.{nm}.hs", (cap, H))
+                hip.call("stonk_gather_rows_bf16", t.data_ptr(), H, rows.data_ptr(), cnt.data_ptr(), hs.data_ptr(), H, H,
+                         cap, st)
+                logits = self.buf(f"l.{nm}.logits", (cap, npad), F32)
+                self.gemm(hs, w(wname), logits, cap, npad, H, flags=hip.EPI_OUT_F32, m_dev=cnt)
+                dl = self.buf(f"l.{nm}.dl", (cap, npad)) if need_backward else None
+                hip.call("stonk_softmax_xent_fwd_bwd", logits.data_ptr(), npad, N, npad, tg.data_ptr(), cnt.data_ptr(),
+                         acc[hi:hi + 1].data_ptr(), hip.ptr(dl), npad, 1.0, self.err.data_ptr(), st)
+                save[nm] = dict(rows=rows, cnt=cnt, hs=hs, dl=dl)
+            dnsp = self.buf("l.dnsp", (B, 2), F32) if need_backward else None
+            hip.call("stonk_nsp_xent_fwd_bwd", nsp.data_ptr(), nsp_labels.data_ptr(), B, 2, acc[2:4].data_ptr(),
+                     hip.ptr(dnsp), 1.0, self.err.data_ptr(), st)
+            hip.call("stonk_loss_finalize", acc[0:1].data_ptr(), cnts[0:1].data_ptr(), acc[1:2].data_ptr(),
+                     cnts[1:2].data_ptr(), acc[2:4].data_ptr(), acc[4:8].data_ptr(), st)
+            out.update(loss=acc[4], masked_lm_loss=acc[5], ent_masked_lm_loss=acc[6], next_sentence_loss=acc[7])
+            save["dnsp"] = dnsp
+        # F7 dense logits (what the reference always materialises: stonkgs_model.py:70-71)
+        if dense_logits:
+            cap = B * half
+            full = self.buf("d.cnt", (1,), I32)
+            full.fill_(cap)
+            for nm, wname, N, off, _ in heads:
+                npad = pad128(N)
+                rows = self.buf(f"d.{nm}.rows", (cap,), I32)
+                rows.copy_((torch.arange(cap, device=self.device, dtype=I32) // half) * S + off +
+                           torch.arange(cap, device=self.device, dtype=I32) % half)
+                hs = self.buf("d.hs", (cap, H))
+                hip.call("stonk_gather_rows_bf16", t.data_ptr(), H, rows.data_ptr(), full.data_ptr(), hs.data_ptr(), H, H,
+                         cap, st)
+                # fresh tensor: handed to the caller, must not alias the workspace
+                logits = torch.empty(cap, npad, dtype=F32, device=self.device)
+                self.gemm(hs, w(wname), logits, cap, npad, H, flags=hip.EPI_OUT_F32)
+                out[f"{nm}_logits"] = logits[:, :N].view(B, half, N)
+        if need_backward:
+            save.update(B=B, attention_mask=attention_mask, token_type_ids=token_type_ids, sum0=sum0, st0=st0,
+                        seq_out=seq_out, pooled=pooled, gt=gt, ut=ut, t=t, stt=stt, p_hid=p_hid, p_att=p_att)
+            self.saved = save
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, gscale: float = 1.0, on_segment_done: Optional[Callable[[str], None]] = None) -> None:
+        """Accumulate d(loss * gscale)/d(param) into the flat gradient buffer. `on_segment_done(name)` fires as
+        soon as the gradients of a contiguous region of the flat buffer are final (DP all-reduce overlap)."""
+        sv = self.saved
+        if sv is None:
+            raise RuntimeError("backward() without a training forward (labels are required)")
+        self.saved = None
+        cfg = self.cfg
+        H, S, half = cfg.hidden_size, cfg.max_position_embeddings, cfg.half_length
+        B = sv["B"]
+        T = B * S
+        st = hip.stream_ptr()
+        P = self.P
+        f, g_, wt = P.view, P.grad_view, P.wt
+        cap = B * half
+        notify = on_segment_done or (lambda name: None)
+        # ---- decoders (label-sparse): dHs = dlogits . W ; dW += dlogits^T . Hs
+        dt = self.buf("b.dt", (T, H))
+        dt.zero_()
+        for nm, wname, N in (("ent", "cls.predictions.entity_decoder.weight", cfg.kg_vocab_size),
+                             ("text", "cls.predictions.text_decoder.weight", cfg.vocab_size)):
+            npad = pad128(N)
+            h = sv[nm]
+            dhs = self.buf("b.dhs", (cap, H))
+            self.gemm(h["dl"], wt[wname], dhs, cap, H, npad, m_dev=h["cnt"], alpha=gscale)
+            hip.call("stonk_scatter_rows_bf16", dhs.data_ptr(), H, h["rows"].data_ptr(), h["cnt"].data_ptr(),
+                     dt.data_ptr(), H, H, st)
+            dlT = self.transpose(h["dl"], cap, npad, "b.dlT", rows_dev=h["cnt"])
+            hsT = self.transpose(h["hs"], cap, H, "b.hsT", rows_dev=h["cnt"])
+            self.gemm(dlT, hsT, g_(wname, padded=True), npad, H, cap if cap % 64 == 0 else (cap + 63) // 64 * 64,
+                      flags=hip.EPI_OUT_F32_ATOMIC, k_dev=h["cnt"], alpha=gscale)
+            notify(wname)
+        # ---- head transform backward
+        dgt = self.buf("b.dgt", (T, H))
+        hip.call("stonk_layernorm_bwd", dt.data_ptr(), sv["gt"].data_ptr(), sv["stt"][0].data_ptr(),
+                 sv["stt"][1].data_ptr(), f("cls.predictions.transform.LayerNorm.weight").data_ptr(), dgt.data_ptr(), 0,
+                 g_("cls.predictions.transform.LayerNorm.weight").data_ptr(),
+                 g_("cls.predictions.transform.LayerNorm.bias").data_ptr(), T, H, 0, 0.0, 0, 0.0, 0, st)
+        dut = self.buf("b.dut", (T, H))
+        hip.call("stonk_gelu_bwd_bf16", dgt.data_ptr(), sv["ut"].data_ptr(), dut.data_ptr(), T * H, st)
+        dutT = self.transpose(dut, T, H, "b.tA_H", colsum=g_("cls.predictions.transform.dense.bias"))
+        seqT = self.transpose(sv["seq_out"], T, H, "b.tB_H")
+        self.wgrad(dutT, seqT, g_("cls.predictions.transform.dense.weight"), H, H, T)
+        dseq = self.buf("b.dseq", (T, H))
+        self.gemm(dut, wt["cls.predictions.transform.dense.weight"], dseq, T, H, H)
+        # ---- NSP + pooler (fp32), pooler gradient lands on position 0 of d(sequence_output)
+        dnsp = sv["dnsp"]
+        if gscale != 1.0:
+            hip.call("stonk_scale_f32", dnsp.data_ptr(), dnsp.numel(), gscale, st)
+        dpooled = self.buf("b.dpooled", (B, H), F32)
+        hip.call("stonk_small_linear_bwd", dnsp.data_ptr(), 0, sv["pooled"].data_ptr(), H,
+                 f("cls.seq_relationship.weight").data_ptr(), g_("cls.seq_relationship.weight").data_ptr(),
+                 g_("cls.seq_relationship.bias").data_ptr(), dpooled.data_ptr(), 0, 0, B, 2, H, hip.SMALL_X_F32, st)
+        hip.call("stonk_small_linear_bwd", dpooled.data_ptr(), sv["pooled"].data_ptr(), sv["seq_out"].data_ptr(), S * H,
+                 f("bert.pooler.dense.weight").data_ptr(), g_("bert.pooler.dense.weight").data_ptr(),
+                 g_("bert.pooler.dense.bias").data_ptr(), 0, dseq.data_ptr(), S * H, B, H, H, hip.SMALL_TANH, st)
+        notify("bert.pooler.dense.bias")
+        # ---- encoder layers, last to first
+        dy = dseq
+        for i in reversed(range(cfg.num_hidden_layers)):
+            prefix = f"bert.encoder.layer.{i}"
+            dy = self.layer_bwd(prefix, dy, B, S, sv["attention_mask"], sv["p_hid"], sv["p_att"], i, sv[prefix])
+            notify(prefix)
+        # ---- embeddings LayerNorm, position / token-type embeddings
+        dsum = self.buf("b.dsum0", (T, H))
+        p_hid = sv["p_hid"]
+        hip.call("stonk_layernorm_bwd", dy.data_ptr(), sv["sum0"].data_ptr(), sv["st0"][0].data_ptr(),
+                 sv["st0"][1].data_ptr(), f("bert.embeddings.LayerNorm.weight").data_ptr(), dsum.data_ptr(), 0,
+                 g_("bert.embeddings.LayerNorm.weight").data_ptr(), g_("bert.embeddings.LayerNorm.bias").data_ptr(), T, H,
+                 hip.LN_DROPOUT if p_hid > 0 else 0, p_hid, self.seed(200, 0), 0.0, 0, st)
+        hip.call("stonk_embed_grad", dsum.data_ptr(), hip.ptr(sv["token_type_ids"]),
+                 g_("bert.embeddings.position_embeddings.weight").data_ptr(),
+                 g_("bert.embeddings.token_type_embeddings.weight").data_ptr(), B, S, H, cfg.type_vocab_size, st)
+        notify("bert.embeddings")

@@ -1,0 +1,378 @@
+"""MI355X-native ``STonKGsForPreTraining``: the reference's module contract on top of the HIP engine.
+
+Mirror of ref:src/stonkgs/models/stonkgs_model.py (same class names, constructor arguments, ``forward`` signature,
+return packing, attributes other code touches, state-dict keys), so that ``stonkgs.models.stonkgs_pretraining``'s
+``Trainer(model=..., ...)`` loop, ``from_pretrained`` and the bs=1 inference helpers work unchanged - but no
+arithmetic runs in torch: ``forward`` hands raw device pointers to ``libstonk_hip.so`` (see ``engine.py``).
+
+Differences a user of the reference will notice (all forced by the offline, GPU-only setting):
+  * ``nlp_model_type`` / ``from_pretrained`` take LOCAL directories, never hub names;
+  * the model is built directly on the GPU (``.to(device)`` to the same device is a no-op);
+  * in training mode the dense logits ([B,256,V] and [B,256,K] = 13 GB at B=64) are not materialised unless
+    asked for (``model.materialize_logits = True``): loss and gradients are identical.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass
+from functools import lru_cache
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _hip as hip
+from .config import STonKGsConfig
+from .engine import Engine
+from .params import FlatStore, _Node, _linear, _param, backbone_specs, build_bert_tree, trainable_specs
+
+SEP_ID, MASK_ID, UNK_ID = 102, 103, 100  # BioBERT vocabulary (ref:stonkgs_model.py:116-118)
+
+
+@dataclass
+class BertForPreTrainingOutputWithPooling:
+    """ref:stonkgs_model.py:30-34 (HF BertForPreTrainingOutput + pooler_output). Indexable like a ModelOutput."""
+
+    loss: Optional[torch.Tensor] = None
+    prediction_logits: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+    seq_relationship_logits: Optional[torch.Tensor] = None
+    hidden_states: Optional[torch.Tensor] = None
+    attentions: Optional[tuple] = None
+    pooler_output: Optional[torch.Tensor] = None
+
+    def to_tuple(self):
+        return tuple(v for v in (self.loss, self.prediction_logits, self.seq_relationship_logits, self.hidden_states,
+                                 self.attentions, self.pooler_output) if v is not None)
+
+    def __getitem__(self, k):
+        return getattr(self, k) if isinstance(k, str) else self.to_tuple()[k]
+
+
+def prepare_df(embedding_path: str, sep: str = "\t") -> Dict[str, "object"]:
+    """ref:src/stonkgs/models/kg_baseline_model.py:270-280: TSV (index column = node name, no header) ->
+    {name: float64 vector}, in file order."""
+    import numpy as np
+
+    out: Dict[str, object] = {}
+    with open(embedding_path) as fh:
+        for line in fh:
+            parts = line.rstrip("\n").split(sep)
+            if len(parts) > 1:
+                out[parts[0]] = np.asarray([float(x) for x in parts[1:]], dtype=np.float64)
+    return out
+
+
+class KGBackbone:
+    """Dict-like view of the dense entity table: ``kg_backbone[i]`` is row i (a device tensor), KeyError outside
+    the table - what ref:stonkgs_model.py:131-141 builds as a Python dict of 175 097 tensors."""
+
+    def __init__(self, table: torch.Tensor):
+        self.table = table
+
+    def __getitem__(self, i: int) -> torch.Tensor:
+        if not 0 <= int(i) < self.table.shape[0]:
+            raise KeyError(i)
+        return self.table[int(i)]
+
+    def __len__(self):
+        return self.table.shape[0]
+
+    def __contains__(self, i):
+        return 0 <= int(i) < self.table.shape[0]
+
+    def keys(self):
+        return range(self.table.shape[0])
+
+
+class STonKGsELMPredictionHead(_Node):
+    """Naming mirror of ref:stonkgs_model.py:37-73 (transform, split text/entity decoders, dead biases)."""
+
+    def __init__(self, config: STonKGsConfig, store: FlatStore, device):
+        super().__init__()
+        H = config.hidden_size
+        tr = _Node()
+        tr.dense = _linear(store, "cls.predictions.transform.dense", True)
+        tr.LayerNorm = _linear(store, "cls.predictions.transform.LayerNorm", True)
+        self.transform = tr
+        self.text_decoder = _linear(store, "cls.predictions.text_decoder", True, bias=False)
+        self.entity_decoder = _linear(store, "cls.predictions.entity_decoder", True, bias=False)
+        self.half_length = config.max_position_embeddings // 2
+        # dead parameters (quirk Q4): declared, serialised, never used by forward, never updated
+        self.bias = nn.Parameter(torch.zeros(config.vocab_size, device=device), requires_grad=False)
+        self.text_bias = nn.Parameter(torch.zeros(config.vocab_size, device=device), requires_grad=False)
+        self.entity_bias = nn.Parameter(torch.zeros(config.kg_vocab_size, device=device), requires_grad=False)
+        dec = _Node()
+        dec.bias = self.bias
+        dec.text_bias = self.text_bias
+        dec.entity_bias = self.entity_bias
+        self.decoder = dec
+
+
+class _StepFunction(torch.autograd.Function):
+    """Makes ``loss.backward()`` (HF Trainer / accelerate) drive the engine's hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, loss):
+        ctx.model = model
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        model = ctx.model
+        model.engine.backward(float(dloss), model._segment_hook)
+        model._reattach_grads()
+        return None, None, None
+
+
+class STonKGsForPreTraining(nn.Module):
+    def __init__(self, config=None, nlp_model_type: Optional[str] = None, kg_embedding_dict_path: Optional[str] = None,
+                 *, kg_embeddings: Optional[torch.Tensor] = None, kg_names=None, device=None, seed: int = 0,
+                 backbone_layers: Optional[int] = None):
+        """:param config: STonKGsConfig / dict / BertConfig-like (the reference ignores its ``config`` and reads the hub;
+            here it is honoured unless ``nlp_model_type`` is a local directory holding config.json)
+        :param nlp_model_type: LOCAL directory of the LM backbone (config.json + pytorch_model.bin|model.safetensors)
+        :param kg_embedding_dict_path: TSV of node2vec embeddings (prepare_df format)
+        :param kg_embeddings: alternative to the TSV: [K, H] tensor in TSV row order (synthetic tables)"""
+        super().__init__()
+        if not torch.cuda.is_available():
+            raise hip.StonkHipError("STonKGsForPreTraining needs an MI355X: the hot path has no CPU fallback")
+        self._device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if nlp_model_type is not None and os.path.isdir(nlp_model_type):
+            cfg = STonKGsConfig.from_pretrained(nlp_model_type)
+            if config is not None:  # keep run-time knobs (dropout) of an explicit config
+                c2 = STonKGsConfig.from_any(config)
+                cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob = c2.hidden_dropout_prob, c2.attention_probs_dropout_prob
+        elif config is not None:
+            cfg = STonKGsConfig.from_any(config)
+        else:
+            raise ValueError("pass a local config, or nlp_model_type = local directory with config.json "
+                             "(hub names cannot be fetched offline)")
+        names = None
+        if kg_embedding_dict_path is not None:
+            d = prepare_df(kg_embedding_dict_path)  # ref:stonkgs_model.py:93
+            names = list(d.keys())
+            import numpy as np
+
+            kg_embeddings = torch.from_numpy(np.stack(list(d.values())))
+        if kg_embeddings is not None:
+            cfg.update({"kg_vocab_size": int(kg_embeddings.shape[0])})  # ref:stonkgs_model.py:97
+            if kg_embeddings.shape[1] != cfg.hidden_size:
+                raise ValueError("KG embedding width must equal hidden_size")
+        self.config = cfg
+        cfg.validate_for_hip()
+        dev = self._device
+        n_bb = cfg.num_hidden_layers if backbone_layers is None else backbone_layers
+        self._store = FlatStore(trainable_specs(cfg), dev, trainable=True)
+        self._bb_store = FlatStore(backbone_specs(cfg, n_bb), dev, trainable=False)
+        # ---- module tree (names only)
+        dead_we = nn.Parameter(torch.zeros(cfg.vocab_size, cfg.hidden_size, device=dev), requires_grad=False)
+        self.bert = build_bert_tree(self._store, "bert", cfg, cfg.num_hidden_layers, True, dead_we)
+        cls = _Node()
+        cls.predictions = STonKGsELMPredictionHead(cfg, self._store, dev)
+        cls.predictions.decoder.weight = dead_we  # tied: cls.predictions.decoder.weight <-> word_embeddings (both dead)
+        cls.seq_relationship = _linear(self._store, "cls.seq_relationship", True)
+        self.cls = cls
+        self.lm_backbone = build_bert_tree(self._bb_store, "lm_backbone", cfg, n_bb, False, None)
+        self.lm_sep_id, self.lm_mask_id, self.lm_unk_id = SEP_ID, MASK_ID, UNK_ID
+        self.engine = Engine(cfg, self._store, self._bb_store, n_bb, dev)
+        self.materialize_logits: Optional[bool] = None  # None = "only when not training"
+        self._segment_hook = None
+        self._anchor = torch.zeros((), device=dev, requires_grad=True)
+        # ---- init weights, KG table
+        self._init_weights(seed)
+        if nlp_model_type is not None and os.path.isdir(nlp_model_type):
+            sd = _load_weights_file(nlp_model_type)
+            if sd is not None:
+                sd = {("lm_backbone." + k[len("bert."):] if k.startswith("bert.") else "lm_backbone." + k): v
+                      for k, v in sd.items() if not k.startswith("cls.")}
+                self.load_state_dict(sd, strict=False, _refresh=False)
+        K = cfg.kg_vocab_size
+        if kg_embeddings is None:
+            g = torch.Generator().manual_seed(seed + 1)
+            kg_embeddings = torch.randn(K, cfg.hidden_size, generator=g, dtype=torch.float64) * 0.3
+        self._kg_rows = kg_embeddings.to(torch.float32).to(dev)  # fp64 -> fp32 RN, as ref:stonkgs_model.py:193-200
+        numeric_indices = [i for i in range(K + 3) if i not in (SEP_ID, MASK_ID, UNK_ID)]
+        names = names if names is not None else [f"node{r}" for r in range(K)] if K <= 4096 else None
+        self.kg_idx_to_name = dict(zip(numeric_indices, names)) if names is not None else _LazyNames(numeric_indices)
+        self._numeric_indices = torch.tensor(numeric_indices, device=dev)
+        self._grad_views = {n: p.grad for n, p in self.named_parameters() if p.requires_grad}
+        self.refresh()
+
+    # -------------------------------------------------------------- construction helpers
+    def _init_weights(self, seed: int) -> None:
+        """BERT init (hf _init_weights: N(0, initializer_range) matrices/embeddings, zero bias, unit LayerNorm)."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        std = self.config.initializer_range
+        with torch.no_grad():
+            for store in (self._store, self._bb_store):
+                for name, (off, shape, _) in store.index.items():
+                    v = store.view(name)
+                    if "LayerNorm.weight" in name:
+                        v.fill_(1.0)
+                    elif name.endswith(".bias") or "LayerNorm.bias" in name:
+                        v.zero_()
+                    else:
+                        v.copy_((torch.randn(shape, generator=g) * std).to(v.device))
+
+    def refresh(self) -> None:
+        """Recompute everything derived from the fp32 masters: bf16 mirrors, W^T copies, the entity table with its
+        three LM special-token rows (quirks Q1/Q2). Called after init / load_state_dict."""
+        eng = self.engine
+        eng.refresh_derived(bf16_mirror=True)
+        K, H = self.config.kg_vocab_size, self.config.hidden_size
+        table = torch.zeros(K + 3, H, dtype=torch.float32, device=self._device)
+        table[self._numeric_indices] = self._kg_rows  # TSV row r -> model index numeric_indices[r]  (Q1)
+        eng.kg_table = table
+        sv = eng.special_vectors()  # (Q2)
+        for sid, vec in sv.items():
+            if sid < K + 3:
+                table[sid] = vec
+        self.kg_backbone = KGBackbone(table)
+
+    # -------------------------------------------------------------- nn.Module plumbing
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.zeros(1, device=self._device))
+        if probe.device != self._device or probe.dtype != torch.float32:
+            raise NotImplementedError("construct STonKGsForPreTraining on its target GPU; parameters are views of flat "
+                                      "HBM buffers and cannot be moved or cast")
+        return self
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False, _refresh: bool = True):
+        res = super().load_state_dict(state_dict, strict=strict)
+        if _refresh:
+            self.refresh()
+        return res
+
+    def _reattach_grads(self) -> None:
+        first = self.cls.predictions.entity_decoder.weight
+        if first.grad is not None:
+            return
+        for name, p in self.named_parameters():
+            if p.requires_grad and p.grad is None:
+                p.grad = self._grad_views[name]
+
+    def named_grad_views(self) -> Dict[str, torch.Tensor]:
+        """name -> view into the flat gradient buffer (stable across zero_grad(set_to_none=True))."""
+        return self._grad_views
+
+    # -------------------------------------------------------------- loaders
+    @classmethod
+    def from_pretrained(cls, path: str, **kwargs) -> "STonKGsForPreTraining":
+        """Local directory in HF layout (config.json + weights). ``kwargs`` go to the constructor, as in HF."""
+        if not os.path.isdir(path):
+            raise FileNotFoundError(f"{path!r}: only local checkpoints can be loaded (no network)")
+        cfg = STonKGsConfig.from_pretrained(path)
+        model = cls(cfg, **kwargs)
+        sd = _load_weights_file(path)
+        if sd is None:
+            raise FileNotFoundError(f"no pytorch_model.bin / model.safetensors under {path!r}")
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        bad = [k for k in missing if "position_ids" not in k]
+        if bad:
+            raise KeyError(f"checkpoint misses {bad[:5]}...")
+        return model
+
+    @classmethod
+    @lru_cache(maxsize=32)
+    def from_default_pretrained(cls, **kwargs) -> "STonKGsForPreTraining":
+        """ref:stonkgs_model.py:143-147 fetches 'stonkgs/stonkgs-150k' from the hub; offline, the checkpoint must be
+        provided locally through $STONKGS_PRETRAINED_DIR."""
+        path = os.environ.get("STONKGS_PRETRAINED_DIR")
+        if not path:
+            raise FileNotFoundError("set STONKGS_PRETRAINED_DIR to a local copy of stonkgs/stonkgs-150k")
+        return cls.from_pretrained(path, **kwargs)
+
+    def save_pretrained(self, path: str) -> None:
+        self.config.save_pretrained(path)
+        torch.save({k: v.detach().cpu() for k, v in self.state_dict().items()}, os.path.join(path, "pytorch_model.bin"))
+
+    # -------------------------------------------------------------- forward
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, masked_lm_labels=None,
+                ent_masked_lm_labels=None, next_sentence_labels=None, return_dict=None, head_mask=None):
+        """ref:stonkgs_model.py:149-258. ``head_mask`` is accepted and ignored (quirk Q8)."""
+        cfg = self.config
+        dev = self._device
+        if input_ids is None:
+            raise ValueError("input_ids is required")
+
+        def prep(t):
+            if t is None:
+                return None
+            t = torch.as_tensor(t)
+            if t.device != dev or t.dtype != torch.long or not t.is_contiguous():
+                t = t.to(device=dev, dtype=torch.long).contiguous()
+            return t
+
+        input_ids, attention_mask, token_type_ids = prep(input_ids), prep(attention_mask), prep(token_type_ids)
+        mlm, elm, nsp = prep(masked_lm_labels), prep(ent_masked_lm_labels), prep(next_sentence_labels)
+        if input_ids.dim() != 2 or input_ids.shape[1] != cfg.max_position_embeddings:
+            raise ValueError(f"input_ids must be [B, {cfg.max_position_embeddings}] (text half | entity half)")
+        have_labels = mlm is not None and elm is not None and nsp is not None
+        training = self.training
+        need_bwd = have_labels and torch.is_grad_enabled() and training
+        dense = self.materialize_logits if self.materialize_logits is not None else not training
+        out = self.engine.forward(input_ids, attention_mask, token_type_ids, mlm if have_labels else None,
+                                  elm if have_labels else None, nsp if have_labels else None, training, dense, need_bwd)
+        total_loss = None
+        if have_labels:
+            total_loss = out["loss"]
+            self.last_loss_terms = tuple(out[k].clone() for k in ("masked_lm_loss", "ent_masked_lm_loss",
+                                                                   "next_sentence_loss"))
+            total_loss = _StepFunction.apply(self._anchor, self, total_loss) if need_bwd else total_loss.clone()
+        prediction_scores = (out.get("text_logits"), out.get("ent_logits"))
+        nsp_logits = out["nsp_logits"].clone()
+        if not return_dict:
+            output = (prediction_scores, nsp_logits)
+            return ((total_loss,) + output) if total_loss is not None else output
+        return BertForPreTrainingOutputWithPooling(
+            loss=total_loss, prediction_logits=prediction_scores, seq_relationship_logits=nsp_logits,
+            hidden_states=out["hidden_states"].float(), attentions=None, pooler_output=out["pooler_output"].clone())
+
+
+    # -------------------------------------------------------------- fused training path (no autograd)
+    def forward_backward(self, inputs: Dict[str, torch.Tensor], gscale: float = 1.0, on_segment_done=None):
+        """forward + hand-written backward in one call: what ``Trainer.training_step`` does through
+        ``loss = model(**inputs)[0]; loss.backward()`` (hf:trainer.py:1892-1963), minus the autograd graph and the
+        host sync on ``dloss``. Gradients are accumulated into the flat buffer; returns the (detached) loss."""
+        dev = self._device
+        t = {k: (v if (torch.is_tensor(v) and v.device == dev and v.dtype == torch.long and v.is_contiguous())
+                 else torch.as_tensor(v).to(device=dev, dtype=torch.long).contiguous()) for k, v in inputs.items()}
+        out = self.engine.forward(t["input_ids"], t.get("attention_mask"), t.get("token_type_ids"),
+                                  t["masked_lm_labels"], t["ent_masked_lm_labels"], t["next_sentence_labels"],
+                                  self.training, False, True)
+        loss = out["loss"].clone()
+        self.engine.backward(gscale, on_segment_done)
+        return loss
+
+
+class _LazyNames:
+    """kg_idx_to_name for synthetic tables too large to name eagerly."""
+
+    def __init__(self, numeric_indices):
+        self._idx = {i: r for r, i in enumerate(numeric_indices)}
+
+    def __getitem__(self, i):
+        return f"node{self._idx[i]}"
+
+    def keys(self):
+        return self._idx.keys()
+
+    def __len__(self):
+        return len(self._idx)
+
+
+def _load_weights_file(path: str) -> Optional[Dict[str, torch.Tensor]]:
+    st = os.path.join(path, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+
+        return load_file(st)
+    pb = os.path.join(path, "pytorch_model.bin")
+    if os.path.exists(pb):
+        return torch.load(pb, map_location="cpu", weights_only=True)
+    return None

@@ -1,0 +1,284 @@
+"""Pre-training driver for the MI355X-native STonKGs: mirror of ref:src/stonkgs/models/stonkgs_pretraining.py
+(``pretrain_stonkgs`` -> ``TrainingArguments`` -> ``Trainer(model, args, train_dataset).train()``) with the HF
+``Trainer`` inner loop (hf:trainer.py:1892-1963 training_step, :1780-1796 clip / optimizer / scheduler / zero_grad)
+restated for one process per GPU:
+
+  forward + hand-written backward (engine)  ->  bucketed RCCL all-reduce of the flat gradient buffer, launched while
+  backward is still producing earlier layers' gradients  ->  ONE fused kernel: global-norm clip + AdamW + bf16
+  weight refresh + gradient zeroing  ->  W^T refresh for the next step's dgrad GEMMs.
+
+Defaults are the reference's: AdamW(lr 1e-4, betas (0.9, 0.999), eps 1e-8, weight_decay 0), max_grad_norm 1.0,
+linear decay to zero over max_steps with no warm-up, gradient_accumulation_steps 1.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from dataclasses import asdict, dataclass, field
+from typing import Callable, Dict, Iterable, List, Optional
+
+import torch
+
+from . import _hip as hip
+from .data import collate, synthetic_batch
+from .params import FlatStore
+
+
+@dataclass
+class TrainingArguments:
+    """The subset of hf TrainingArguments the reference sets (ref:stonkgs_pretraining.py:171-193) or relies on."""
+
+    output_dir: str = "stonkgs_pretraining_out"
+    per_device_train_batch_size: int = 8
+    max_steps: int = 200
+    learning_rate: float = 1e-4
+    gradient_accumulation_steps: int = 1
+    max_grad_norm: float = 1.0
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    adam_epsilon: float = 1e-8
+    weight_decay: float = 0.0
+    warmup_steps: int = 0
+    logging_steps: int = 100
+    save_steps: int = 5000
+    save_total_limit: int = 5
+    seed: int = 42
+    ddp_bucket_mb: float = 64.0
+
+
+def linear_schedule_lr(base_lr: float, step: int, max_steps: int, warmup: int = 0) -> float:
+    """hf get_linear_schedule_with_warmup: learning rate used by optimizer step number `step` (0-based)."""
+    if step < warmup:
+        return base_lr * step / max(1, warmup)
+    return base_lr * max(0.0, (max_steps - step) / max(1, max_steps - warmup))
+
+
+class FusedAdamW:
+    """clip_grad_norm_ + AdamW + zero_grad over the model's flat fp32 buffers in two kernel launches."""
+
+    def __init__(self, store: FlatStore, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0):
+        self.store = store
+        self.betas, self.eps, self.weight_decay, self.max_grad_norm = betas, eps, weight_decay, max_grad_norm
+        self.m = torch.zeros_like(store.data)
+        self.v = torch.zeros_like(store.data)
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=store.data.device)
+        self.step_count = 0
+
+    def step(self, lr: float, grad_scale: float = 1.0) -> None:
+        s = self.store
+        st = hip.stream_ptr()
+        self.step_count += 1
+        b1, b2 = self.betas
+        self.gnorm_sq.zero_()
+        hip.call("stonk_sumsq_f32", s.grad.data_ptr(), s.numel, self.gnorm_sq.data_ptr(), st)
+        hip.call("stonk_adamw_step", s.data.data_ptr(), s.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                 s.bf16.data_ptr(), s.numel, lr, b1, b2, self.eps, self.weight_decay, 1.0 - b1 ** self.step_count,
+                 1.0 - b2 ** self.step_count, self.gnorm_sq.data_ptr(), self.max_grad_norm, grad_scale, st)
+
+    def last_grad_norm(self, grad_scale: float = 1.0) -> float:
+        return float(self.gnorm_sq.sqrt().item()) * grad_scale
+
+    def zero_grad(self) -> None:
+        self.store.grad.zero_()
+
+    def state_dict(self):
+        return {"step": self.step_count, "m": self.m.cpu(), "v": self.v.cpu()}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+
+
+def plan_buckets(segment_ends: List[int], bucket_elems: int) -> List[tuple]:
+    """Cut the flat gradient buffer into contiguous [lo, hi) buckets whose boundaries are segment ends (a segment =
+    what one backward notification finalises), each at least `bucket_elems` long except possibly the last."""
+    buckets, lo = [], 0
+    for end in segment_ends:
+        if end - lo >= bucket_elems:
+            buckets.append((lo, end))
+            lo = end
+    if segment_ends and lo < segment_ends[-1]:
+        buckets.append((lo, segment_ends[-1]))
+    return buckets
+
+
+class GradSynchronizer:
+    """Data-parallel gradient averaging over RCCL (torch.distributed backend "nccl" on ROCm; "gloo" on CPU tests).
+
+    The flat gradient buffer is laid out in backward-completion order (params.py), so when the engine reports
+    "segment X done" every byte before X's end is final: the bucket ending there is all-reduced immediately, on
+    RCCL's own stream, while the compute stream continues with the next layer's backward. xGMI is point-to-point
+    (7 links/GPU), so few large buckets (default 64 MB) beat DDP's 25 MB default. Averaging is folded into the
+    optimizer kernel's grad_scale (sum here, 1/world there)."""
+
+    def __init__(self, grad: torch.Tensor, segments: Dict[str, int], bucket_mb: float = 64.0, group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.grad = grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.segment_end = dict(segments)  # notification name -> end offset in the flat buffer
+        ends = sorted(set(segments.values()))
+        self.buckets = plan_buckets(ends, int(bucket_mb * (1 << 20) / 4))
+        self._next = 0
+        self._works = []
+
+    def on_segment_done(self, name: str) -> None:
+        if self.world == 1:
+            return
+        end = self.segment_end.get(name)
+        if end is None:
+            return
+        while self._next < len(self.buckets) and self.buckets[self._next][1] <= end:
+            lo, hi = self.buckets[self._next]
+            self._works.append(self.dist.all_reduce(self.grad[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group,
+                                                    async_op=True))
+            self._next += 1
+
+    def finish(self) -> float:
+        """Flush remaining buckets, wait for all of them; returns the factor that turns the sum into the mean."""
+        if self.world > 1:
+            while self._next < len(self.buckets):
+                lo, hi = self.buckets[self._next]
+                self._works.append(self.dist.all_reduce(self.grad[lo:hi], op=self.dist.ReduceOp.SUM,
+                                                        group=self.group, async_op=True))
+                self._next += 1
+            for w in self._works:
+                w.wait()
+        self._works, self._next = [], 0
+        return 1.0 / self.world
+
+
+def segment_ends_for(model) -> Dict[str, int]:
+    """Map the engine's backward notifications to end offsets in the flat gradient buffer."""
+    store, cfg = model._store, model.config
+    seg = {"cls.predictions.entity_decoder.weight": store.span("cls.predictions.entity_decoder.weight")[1],
+           "cls.predictions.text_decoder.weight": store.span("cls.predictions.text_decoder.weight")[1],
+           "bert.pooler.dense.bias": store.span("bert.pooler.dense.bias")[1]}
+    for i in range(cfg.num_hidden_layers):
+        seg[f"bert.encoder.layer.{i}"] = store.span(f"bert.encoder.layer.{i}.output.LayerNorm.bias")[1]
+    seg["bert.embeddings"] = store.numel
+    return seg
+
+
+class Trainer:
+    """``Trainer(model=model, args=training_args, train_dataset=ds).train()`` as the reference calls it
+    (ref:stonkgs_pretraining.py:215-223). `train_dataset`: sequence of row dicts with the six schema columns, or any
+    iterable of already collated batches."""
+
+    def __init__(self, model, args: Optional[TrainingArguments] = None, train_dataset=None,
+                 data_collator: Callable = collate):
+        import torch.distributed as dist
+
+        self.model = model
+        self.args = args or TrainingArguments()
+        self.train_dataset = train_dataset
+        self.data_collator = data_collator
+        self.optimizer = FusedAdamW(model._store, (self.args.adam_beta1, self.args.adam_beta2), self.args.adam_epsilon,
+                                    self.args.weight_decay, self.args.max_grad_norm)
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.sync = GradSynchronizer(model._store.grad, segment_ends_for(model), self.args.ddp_bucket_mb)
+        self.global_step = 0
+        self._micro = 0
+        self.log_history: List[dict] = []
+
+    # hf:trainer.py:1892-1963 (+ the optimizer half of :1780-1796 when the accumulation window closes)
+    def training_step(self, model, inputs: Dict[str, torch.Tensor]) -> torch.Tensor:
+        model.train()
+        gas = self.args.gradient_accumulation_steps
+        self._micro += 1
+        last = self._micro % gas == 0
+        hook = self.sync.on_segment_done if last else None
+        loss = model.forward_backward(inputs, gscale=1.0 / gas, on_segment_done=hook)
+        if last:
+            scale = self.sync.finish()
+            lr = linear_schedule_lr(self.args.learning_rate, self.global_step, self.args.max_steps, self.args.warmup_steps)
+            self.optimizer.step(lr, grad_scale=scale)
+            model.engine.refresh_derived(bf16_mirror=False)
+            self.global_step += 1
+        return loss
+
+    def _batches(self) -> Iterable[Dict[str, torch.Tensor]]:
+        ds, bs = self.train_dataset, self.args.per_device_train_batch_size
+        if ds is None:
+            raise ValueError("Trainer.train() needs a train_dataset")
+        if isinstance(ds, (list, tuple)) and ds and isinstance(ds[0], dict) and not torch.is_tensor(ds[0]["input_ids"]):
+            g = torch.Generator().manual_seed(self.args.seed)
+            while True:
+                perm = torch.randperm(len(ds), generator=g).tolist()
+                shard = perm[self.rank::self.world]  # DistributedSampler-style sharding
+                for i in range(0, len(shard) - bs + 1, bs):
+                    yield self.data_collator([ds[j] for j in shard[i:i + bs]])
+        else:
+            while True:
+                for b in ds:
+                    yield b
+
+    def train(self, resume_from_checkpoint: Optional[str] = None):
+        if resume_from_checkpoint:
+            self.load_checkpoint(resume_from_checkpoint)
+        it = iter(self._batches())
+        t0 = time.time()
+        while self.global_step < self.args.max_steps:
+            loss = self.training_step(self.model, next(it))
+            if self._micro % self.args.gradient_accumulation_steps == 0:
+                if self.global_step % self.args.logging_steps == 0 or self.global_step == self.args.max_steps:
+                    self.model.engine.check_errors()
+                    self.log_history.append({"step": self.global_step, "loss": float(loss), "time": time.time() - t0})
+                if self.args.save_steps and self.global_step % self.args.save_steps == 0 and self.rank == 0:
+                    self.save_checkpoint()
+        return {"global_step": self.global_step, "training_loss": float(loss)}
+
+    # checkpoint / resume (ref:stonkgs_pretraining.py:185-186,196-223: save_steps, save_total_limit, resume)
+    def save_checkpoint(self) -> str:
+        d = os.path.join(self.args.output_dir, f"checkpoint-{self.global_step}")
+        self.model.save_pretrained(d)
+        torch.save(self.optimizer.state_dict(), os.path.join(d, "optimizer.pt"))
+        with open(os.path.join(d, "trainer_state.json"), "w") as fh:
+            json.dump({"global_step": self.global_step, "log_history": self.log_history, "args": asdict(self.args)}, fh)
+        ckpts = sorted((c for c in os.listdir(self.args.output_dir) if c.startswith("checkpoint-")),
+                       key=lambda c: int(c.split("-")[1]))
+        for old in ckpts[:-self.args.save_total_limit]:
+            import shutil
+
+            shutil.rmtree(os.path.join(self.args.output_dir, old))
+        return d
+
+    def load_checkpoint(self, d: str) -> None:
+        from .stonkgs_model import _load_weights_file
+
+        self.model.load_state_dict(_load_weights_file(d), strict=False)
+        self.optimizer.load_state_dict(torch.load(os.path.join(d, "optimizer.pt"), weights_only=True))
+        with open(os.path.join(d, "trainer_state.json")) as fh:
+            self.global_step = json.load(fh)["global_step"]
+
+    def save_model(self, output_dir: Optional[str] = None) -> None:
+        self.model.save_pretrained(output_dir or self.args.output_dir)
+
+
+def get_last_checkpoint(folder: str) -> Optional[str]:
+    if not os.path.isdir(folder):
+        return None
+    c = [x for x in os.listdir(folder) if x.startswith("checkpoint-") and x.split("-")[1].isdigit()]
+    return os.path.join(folder, max(c, key=lambda x: int(x.split("-")[1]))) if c else None
+
+
+def pretrain_stonkgs(model, train_dataset, batch_size: int = 8, lr: float = 1e-4, max_steps: int = 10000,
+                     gradient_accumulation_steps: int = 1, logging_steps: int = 100, training_dir: str = "pretraining",
+                     overwrite_output_dir: bool = False):
+    """ref:stonkgs_pretraining.py:103-230 without mlflow / hub: build args, resume if a checkpoint exists (raise if
+    the directory is non-empty without one, as the reference does :203-207), train, save."""
+    args = TrainingArguments(output_dir=training_dir, per_device_train_batch_size=batch_size, max_steps=max_steps,
+                             learning_rate=lr, gradient_accumulation_steps=gradient_accumulation_steps,
+                             logging_steps=logging_steps)
+    last = get_last_checkpoint(training_dir)
+    if last is None and os.path.isdir(training_dir) and os.listdir(training_dir) and not overwrite_output_dir:
+        raise ValueError(f"Output directory ({training_dir}) already exists and is not empty.")
+    trainer = Trainer(model=model, args=args, train_dataset=train_dataset)
+    result = trainer.train(resume_from_checkpoint=last)
+    trainer.save_model()
+    return trainer, result

@@ -1,0 +1,67 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient path (bucketed all-reduce of the flat gradient buffer in
+backward-completion order, averaging folded into the optimizer scale) and the dataset sharding of the Trainer."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from stonkgs_amd.stonkgs_pretraining import GradSynchronizer, plan_buckets
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 5000
+        grad = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        segments = {"a": 1200, "b": 1300, "c": 3000, "d": n}
+        sync = GradSynchronizer(grad, segments, bucket_mb=1000 * 4 / (1 << 20))  # 1000-element buckets
+        assert sync.buckets == plan_buckets([1200, 1300, 3000, n], 1000)
+        # backward reports segments front to back; everything before a reported end must be reducible at once
+        sync.on_segment_done("a")
+        launched_after_a = len(sync._works)
+        sync.on_segment_done("b")
+        sync.on_segment_done("c")
+        scale = sync.finish()
+        expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+        ok = torch.equal(grad, expect) and scale == 1.0 / world and launched_after_a == 1
+        # second step reuses the synchronizer
+        grad.fill_(float(rank))
+        for name in ("a", "b", "c", "d"):
+            sync.on_segment_done(name)
+        sync.finish()
+        ok = ok and torch.equal(grad, torch.full((n,), float(sum(range(world)))))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_single_process_is_a_noop():
+    grad = torch.ones(10)
+    s = GradSynchronizer(grad, {"x": 10})
+    s.on_segment_done("x")
+    assert s.finish() == 1.0 and torch.equal(grad, torch.ones(10))

@@ -1,0 +1,114 @@
+"""CPU (no GPU): host-side logic of the product - masking / batch schema against reference-made vectors, config,
+learning-rate schedule, bucket planning, the C-ABI library's exported symbols, loud failure without a GPU."""
+import ctypes
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from stonkgs_amd import _hip
+from stonkgs_amd import data as D
+from stonkgs_amd.config import STonKGsConfig
+from stonkgs_amd.stonkgs_pretraining import linear_schedule_lr, plan_buckets
+from tests.golden_util import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_masking_bit_exact_with_reference_vectors():
+    gold = dict(np.load(GOLDEN + "/masking.npz"))
+    for seed in (0, 1, 1234):
+        random.seed(seed)
+        t_in, t_lab = D.replace_mlm_tokens(list(range(1000, 1256)), 28996)
+        e_in, e_lab = D.replace_mlm_tokens([(7 * i) % 175094 for i in range(256)], 175094)
+        assert t_in == gold[f"text_in_{seed}"].tolist() and t_lab == gold[f"text_lab_{seed}"].tolist()
+        assert e_in == gold[f"ent_in_{seed}"].tolist() and e_lab == gold[f"ent_lab_{seed}"].tolist()
+        random.seed(seed)
+        rows = [{"input_ids": list(range(i * 10, i * 10 + 8)), "attention_mask": [1] * 8,
+                 "token_type_ids": [0] * 4 + [1] * 4, "masked_lm_labels": [-100] * 4, "ent_masked_lm_labels": [i] * 4,
+                 "next_sentence_labels": 0} for i in range(8)]
+        neg = D.add_negative_nsp_samples(rows, text_part_length=4)
+        assert [r["input_ids"] for r in neg] == gold[f"neg_input_ids_{seed}"].tolist()
+        assert [r["ent_masked_lm_labels"] for r in neg] == gold[f"neg_ent_labels_{seed}"].tolist()
+        assert [r["next_sentence_labels"] for r in neg] == gold[f"neg_nsp_{seed}"].tolist()
+
+
+def test_empty_and_short_sequences_mask_nothing():
+    random.seed(0)
+    assert D.replace_mlm_tokens([], 10) == ([], [])
+    inp, lab = D.replace_mlm_tokens([5, 6, 7], 10)  # int(3 * 0.15) = 0 positions
+    assert inp == [5, 6, 7] and lab == [-100] * 3
+
+
+def test_synthetic_batch_schema():
+    b = D.synthetic_batch(6, 28996, 175094, 512, seed=3)
+    assert b["input_ids"].shape == (6, 512) and b["masked_lm_labels"].shape == (6, 256)
+    assert (b["attention_mask"][:, 256:] == 1).all() and (b["token_type_ids"][:, 256:] == 1).all()
+    assert ((b["ent_masked_lm_labels"] != -100).sum(1) == 38).all()  # int(256 * 0.15)
+    assert (b["input_ids"][:, 383] == 102).sum() >= 4 and b["input_ids"].max() < 175094
+    # padded text positions carry no label and no attention
+    pad = b["attention_mask"][:, :256] == 0
+    assert (b["masked_lm_labels"][pad] == -100).all() and (b["input_ids"][:, :256][pad] == 0).all()
+    b2 = D.synthetic_batch(6, 28996, 175094, 512, seed=3)
+    assert all(torch.equal(b[k], b2[k]) for k in b)
+    ex = D.example_batch()
+    assert ex["input_ids"].shape == (3, 512) and ex["attention_mask"][:, :256].sum(1).tolist() == [13, 15, 14]
+
+
+def test_config_validation_and_roundtrip(tmp_path):
+    c = STonKGsConfig()
+    c.validate_for_hip()
+    assert c.half_length == 256 and c.head_dim == 64
+    with pytest.raises(ValueError):
+        STonKGsConfig(hidden_size=64, num_attention_heads=4).validate_for_hip()
+    c.update({"kg_vocab_size": 123})
+    c.save_pretrained(str(tmp_path))
+    assert STonKGsConfig.from_pretrained(str(tmp_path)).kg_vocab_size == 123
+    with pytest.raises(FileNotFoundError):
+        STonKGsConfig.from_pretrained("dmis-lab/biobert-v1.1")  # hub names cannot be resolved offline
+
+
+def test_linear_schedule_matches_hf_lambda():
+    for step in (0, 1, 100, 199, 200, 250):
+        assert linear_schedule_lr(1e-4, step, 200) == pytest.approx(1e-4 * max(0.0, (200 - step) / 200))
+    assert linear_schedule_lr(1.0, 5, 100, warmup=10) == pytest.approx(0.5)
+
+
+def test_plan_buckets_covers_buffer_exactly():
+    ends = [100, 150, 160, 400, 410, 1000]
+    b = plan_buckets(ends, 200)
+    assert b[0][0] == 0 and b[-1][1] == 1000
+    assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+    assert all(hi in ends for _, hi in b)
+    assert plan_buckets([10], 100) == [(0, 10)] and plan_buckets([], 10) == []
+
+
+def test_library_exports_every_declared_symbol():
+    """include/stonk_hip.h, the ctypes table and the built .so agree (no compute call: no GPU here)."""
+    header = open(os.path.join(ROOT, "include", "stonk_hip.h")).read()
+    declared = set(re.findall(r"^int (stonk_\w+)\(", header, flags=re.M))
+    assert declared == set(_hip.exported_symbols())
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _hip.lib().stonk_abi_version() == 1
+
+
+def test_bad_arguments_are_rejected_without_touching_the_gpu():
+    lib = _hip.lib()
+    assert lib.stonk_gemm_nt_bf16(0, 0, 0, 0, 0, 0, 1, 128, 64, 0, 0, 0, 0, 0, 0, 1.0, 1, 0, 0, 0.0, 0, 0) == -1
+    assert lib.stonk_layernorm_fwd(16, 16, 16, 16, 0, 0, 4, 7, 1e-12, 0, 0.0, 0, 0) == -2
+    assert lib.stonk_attention_fwd(16, 16, 16, 192, 0, 16, 64, 0, 1, 1, 100, 64, 0.125, 0.0, 0, 0) == -2
+    with pytest.raises(_hip.StonkHipError):
+        _hip.check(-2, "x")
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_model_fails_loudly_without_gpu():
+    from stonkgs_amd.stonkgs_model import STonKGsForPreTraining
+
+    with pytest.raises(_hip.StonkHipError):
+        STonKGsForPreTraining(STonKGsConfig())

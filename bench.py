@@ -40,6 +40,22 @@ def parse():
     return ap.parse_args()
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores() -> int:
+    """CPU threads this process may actually use (affinity mask and cgroup quota, not the machine's core count)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(cfg, seconds_budget=25.0):
     """The oracle (CPU restatement of the reference's HuggingFace path, pinned by tests/test_oracle_golden.py) timed
     on this host's cores: full training steps at the SAME model shape on a bounded sample (B = 2)."""
@@ -49,18 +65,22 @@ def cpu_baseline(cfg, seconds_budget=25.0):
     ocfg = orc.OracleConfig(vocab_size=cfg.vocab_size, kg_vocab_size=cfg.kg_vocab_size, hidden_size=cfg.hidden_size,
                             num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
                             intermediate_size=cfg.intermediate_size, max_position_embeddings=cfg.max_position_embeddings)
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads, building fp32 weights")
     sd = orc.init_state_dict(ocfg, seed=0, bf16_exact=False)
     table = torch.randn(ocfg.kg_vocab_size + 3, ocfg.hidden_size) * 0.3
     B = 2
     batch = synthetic_batch(B, ocfg.vocab_size, ocfg.kg_vocab_size, ocfg.max_position_embeddings, seed=4321)
     state = orc.AdamState()
+    tw = time.time()
     orc.train_step(sd, ocfg, table, batch, state)  # warm-up (allocations, oneDNN primitive caches)
+    log(f"cpu_baseline: warm-up step {time.time() - tw:.1f} s")
     n, t0 = 0, time.time()
-    while n < 2 or (time.time() - t0 < seconds_budget and n < 8):
+    while n < 1 or (time.time() - t0 < seconds_budget and n < 8):
         orc.train_step(sd, ocfg, table, batch, state)
         n += 1
+        log(f"cpu_baseline: step {n} at {time.time() - t0:.1f} s")
     dt = time.time() - t0
     return {"value": B * n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} full fp32 training steps of the CPU oracle at the same model shape, batch {B} "
@@ -84,6 +104,7 @@ def main():
     from stonkgs_amd.stonkgs_model import STonKGsForPreTraining
     from stonkgs_amd.stonkgs_pretraining import Trainer, TrainingArguments
 
+    log(f"rank {rank}/{world}: building model")
     cfg = STonKGsConfig()  # 12L / 768h / 12 heads / 3072 / 512 positions / V 28996 / K 175094, dropout 0.1
     model = STonKGsForPreTraining(cfg, seed=0)  # same seed on every rank: replicas start identical (as DDP broadcasts)
     trainer = Trainer(model, TrainingArguments(per_device_train_batch_size=args.batch, max_steps=200, learning_rate=1e-4))
@@ -97,10 +118,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log("model + batches ready; warm-up")
     loss = None
     for i in range(args.warmup):
         loss = trainer.training_step(model, batches[i % len(batches)])
+        if i == 0:
+            torch.cuda.synchronize()
+            log(f"first step done, loss {float(loss):.4f}")
     barrier()
+    log("timed region")
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = trainer.training_step(model, batches[i % len(batches)])
@@ -112,6 +138,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss)
+    log(f"timed: {dt / args.steps * 1e3:.2f} ms/step, loss {final_loss:.4f}")
 
     roofline = None
     if not args.no_roofline and rank == 0:

@@ -30,12 +30,20 @@ class GemmTimer:
     """Optional per-launch HIP-event timing of the GEMM kernel (bench.py roofline leg)."""
 
     def __init__(self):
-        self.records = []  # (start_event, end_event, flops)
+        self.records = []  # (start_event, end_event, M, N, K, m_dev, k_dev)
 
     def summarize(self):
+        """Algorithmic FLOPs use the rows / contraction length that exist at run time (device-side counts of the
+        label-sparse decoders), not the launch capacity."""
         torch.cuda.synchronize()
-        tot_t = sum(s.elapsed_time(e) for s, e, _ in self.records) * 1e-3
-        tot_f = sum(f for _, _, f in self.records)
+        tot_t = tot_f = 0.0
+        for s, e, M, N, K, m_dev, k_dev in self.records:
+            tot_t += s.elapsed_time(e) * 1e-3
+            if m_dev is not None:
+                M = min(M, int(m_dev.item()))
+            if k_dev is not None:
+                K = min(K, int(k_dev.item()))
+            tot_f += 2.0 * M * N * K
         return {"launches": len(self.records), "seconds": tot_t, "flops": tot_f}
 
 
@@ -90,7 +98,7 @@ class Engine:
                  seed & 0xFFFFFFFF, st)
         if timed:
             e1.record()
-            self.gemm_timer.records.append((e0, e1, 2.0 * M * N * K))
+            self.gemm_timer.records.append((e0, e1, M, N, K, m_dev, k_dev))
 
     @staticmethod
     def _split_k(M, N, K) -> int:

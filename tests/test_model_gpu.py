@@ -108,7 +108,9 @@ def test_two_optimizer_steps_match_reference_golden(hip):
         if "key.bias" not in k:  # analytically zero gradient: Adam turns rounding noise into +-lr steps on both sides
             cos = torch.nn.functional.cosine_similarity(got_delta.flatten(), ref_delta.flatten(), dim=0).item()
             assert cos > 0.9, (k, cos)
-        assert _rel(params[k], gold["after2::" + k]) < 1e-3, k
+            assert _rel(params[k], gold["after2::" + k]) < 1e-3, k
+        else:  # two Adam steps of at most lr each, in either direction, on both sides
+            assert (params[k].detach().cpu() - torch.from_numpy(gold["after2::" + k])).abs().max() <= 4.5e-4
 
 
 def test_against_oracle_on_fresh_batch_and_masks(g2):

@@ -104,6 +104,8 @@ int stonk_gather_rows_bf16(const void* src, int64_t ld_src, const int* rows, con
                            int64_t ld_dst, int cols, int64_t cap, void* stream);
 int stonk_scatter_rows_bf16(const void* src, int64_t ld_src, const int* rows, const int* count_dev, void* dst,
                             int64_t ld_dst, int cols, void* stream);
+int stonk_scatter_rows_f32_to_bf16(const float* src, int64_t ld_src, const int* rows, const int* count_dev, void* dst,
+                                   int64_t ld_dst, int cols, void* stream);
 
 /* Per labelled row: loss_sum += logsumexp(logits[row,:ncols]) - logits[row,target];
  * dlogits (bf16, nullable) = (softmax - onehot) * grad_scale / count. Bit 3 of *err_flag: target out of range. */

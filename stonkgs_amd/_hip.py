@@ -50,6 +50,7 @@ _SIGNATURES = {
     "stonk_label_compact": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "stonk_gather_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _vp],
     "stonk_scatter_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp],
+    "stonk_scatter_rows_f32_to_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp],
     "stonk_softmax_xent_fwd_bwd": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _f32, _vp, _vp],
     "stonk_nsp_xent_fwd_bwd": [_vp, _vp, _i32, _i32, _vp, _vp, _f32, _vp, _vp],
     "stonk_loss_finalize": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],

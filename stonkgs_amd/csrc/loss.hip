@@ -84,6 +84,23 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16* __restric
   }
 }
 
+// fp32 source variant (split-K dgrad of the decoders accumulates in fp32): dst[rows[i]] = bf16(src[i])
+__global__ __launch_bounds__(256) void scatter_rows_f32_kernel(const float* __restrict__ src, long ld_src,
+                                                               const int* __restrict__ rows,
+                                                               const int* __restrict__ count, bf16* __restrict__ dst,
+                                                               long ld_dst, int cols) {
+  const int cnt = *count;
+  const int nch = cols >> 3;
+  const long total = (long)cnt * nch;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / nch;
+    const int c = (int)(i - r * nch);
+    const f32x4 a = *(const f32x4*)(src + r * ld_src + c * 8), b = *(const f32x4*)(src + r * ld_src + c * 8 + 4);
+    bf16x8 o = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+    *(bf16x8*)(dst + (long)rows[r] * ld_dst + c * 8) = o;
+  }
+}
+
 // One block per labelled row: online (max, sum-exp) sweep of the fp32 logits, then a second sweep writes
 // dlogits = (softmax - onehot) * gscale / count as bf16 (columns [ncols, npad) = 0). loss_sum += lse - x[target].
 __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits, long ld, int ncols, int npad,
@@ -242,6 +259,15 @@ extern "C" int stonk_scatter_rows_bf16(const void* src, int64_t ld_src, const in
   STONK_CHECK_ARG(cols > 0 && cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0, STONK_EALIGN);
   hipLaunchKernelGGL(scatter_rows_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (long)ld_src,
                      rows, count_dev, (bf16*)dst, (long)ld_dst, cols);
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_scatter_rows_f32_to_bf16(const float* src, int64_t ld_src, const int* rows, const int* count_dev,
+                                             void* dst, int64_t ld_dst, int cols, void* stream) {
+  STONK_CHECK_ARG(src && rows && count_dev && dst, STONK_EINVAL);
+  STONK_CHECK_ARG(cols > 0 && cols % 8 == 0 && ld_src % 4 == 0 && ld_dst % 8 == 0, STONK_EALIGN);
+  hipLaunchKernelGGL(scatter_rows_f32_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, src, (long)ld_src, rows,
+                     count_dev, (bf16*)dst, (long)ld_dst, cols);
   return stonk_launch_status();
 }
 

@@ -59,27 +59,40 @@ __global__ __launch_bounds__(256) void small_linear_wgrad_kernel(const float* __
 
 // dx[m][k] = sum_n dpre[m][n] W[n][k]; written as fp32 (dx_f32[m*K + k]) and/or ADDED into a bf16 row
 // (dx_bf16[m*ld_dxb + k] += ...: the pooler's gradient lands on position 0 of d(sequence_output)).
+// grid = (ceil(K/256), M): dpre[m][:] is staged in LDS once per block, W is read coalesced along k.
 __global__ __launch_bounds__(256) void small_linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                  const float* __restrict__ W, float* __restrict__ dx_f32,
                                                                  bf16* __restrict__ dx_bf16, long ld_dxb, int M, int N,
                                                                  int K, int act) {
+  extern __shared__ __attribute__((aligned(16))) float dpre[];
   const bool th = act & STONK_SMALL_TANH;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)M * K; i += (long)gridDim.x * 256) {
-    const int m = (int)(i / K), k = (int)(i - (long)m * K);
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) {
-      float d = dy[(long)m * N + n];
-      if (th) {
-        const float yy = y[(long)m * N + n];
-        d *= 1.f - yy * yy;
-      }
-      acc += d * W[(long)n * K + k];
+  const int m = blockIdx.y;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float d = dy[(long)m * N + n];
+    if (th) {
+      const float yy = y[(long)m * N + n];
+      d *= 1.f - yy * yy;
     }
-    if (dx_f32) dx_f32[i] = acc;
-    if (dx_bf16) {
-      bf16* p = dx_bf16 + (long)m * ld_dxb + k;
-      *p = (bf16)((float)*p + acc);
-    }
+    dpre[n] = d;
+  }
+  __syncthreads();
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int n = 0;
+  for (; n + 4 <= N; n += 4) {
+    a0 += dpre[n] * W[(long)n * K + k];
+    a1 += dpre[n + 1] * W[(long)(n + 1) * K + k];
+    a2 += dpre[n + 2] * W[(long)(n + 2) * K + k];
+    a3 += dpre[n + 3] * W[(long)(n + 3) * K + k];
+  }
+  for (; n < N; ++n) a0 += dpre[n] * W[(long)n * K + k];
+  const float acc = (a0 + a1) + (a2 + a3);
+  const long i = (long)m * K + k;
+  if (dx_f32) dx_f32[i] = acc;
+  if (dx_bf16) {
+    bf16* p = dx_bf16 + (long)m * ld_dxb + k;
+    *p = (bf16)((float)*p + acc);
   }
 }
 
@@ -109,9 +122,8 @@ extern "C" int stonk_small_linear_bwd(const float* dy, const float* y, const voi
   hipLaunchKernelGGL(small_linear_wgrad_kernel, dim3((unsigned)((nk + 255) / 256 < 4096 ? (nk + 255) / 256 : 4096)),
                      dim3(256), 0, st, dy, y, x, (long)ldx, dW, db, M, N, K, act);
   if (dx_f32 || dx_bf16_accum) {
-    long mk = (long)M * K;
-    hipLaunchKernelGGL(small_linear_dgrad_kernel, dim3((unsigned)((mk + 255) / 256 < 4096 ? (mk + 255) / 256 : 4096)),
-                       dim3(256), 0, st, dy, y, W, dx_f32, (bf16*)dx_bf16_accum, (long)ld_dxb, M, N, K, act);
+    hipLaunchKernelGGL(small_linear_dgrad_kernel, dim3((K + 255) / 256, M), dim3(256), (size_t)N * sizeof(float), st, dy,
+                       y, W, dx_f32, (bf16*)dx_bf16_accum, (long)ld_dxb, M, N, K, act);
   }
   return stonk_launch_status();
 }

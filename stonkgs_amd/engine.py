@@ -408,9 +408,12 @@ class Engine:
                              ("text", "cls.predictions.text_decoder.weight", cfg.vocab_size)):
             npad = pad128(N)
             h = sv[nm]
-            dhs = self.buf("b.dhs", (cap, H))
-            self.gemm(h["dl"], wt[wname], dhs, cap, H, npad, m_dev=h["cnt"], alpha=gscale)
-            hip.call("stonk_scatter_rows_bf16", dhs.data_ptr(), H, h["rows"].data_ptr(), h["cnt"].data_ptr(),
+            # few output tiles (count/128 x H/128), very long contraction (the vocabulary): split-K into fp32
+            dhs = self.buf("b.dhs32", (cap, H), F32)
+            dhs.zero_()
+            self.gemm(h["dl"], wt[wname], dhs, cap, H, npad, flags=hip.EPI_OUT_F32_ATOMIC,
+                      split_k=max(1, min(16, npad // 2048)), m_dev=h["cnt"], alpha=gscale)
+            hip.call("stonk_scatter_rows_f32_to_bf16", dhs.data_ptr(), H, h["rows"].data_ptr(), h["cnt"].data_ptr(),
                      dt.data_ptr(), H, H, st)
             dlT = self.transpose(h["dl"], cap, npad, "b.dlT", rows_dev=h["cnt"])
             hsT = self.transpose(h["hs"], cap, H, "b.hsT", rows_dev=h["cnt"])

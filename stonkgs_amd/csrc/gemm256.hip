@@ -1,0 +1,372 @@
+// bf16 MFMA GEMM, 256x256x64 tiles, persistent, LDS-DMA pipelined across barriers AND across output tiles.
+// Same contract as gemm_bf16.hip (C = epilogue(alpha * A[M,K] . B[N,K]^T)); used for the large launches of the
+// STonKGs step, where the 128x128 two-barrier kernel tops out at ~0.65-0.95 PFLOP/s.
+//
+// Structure (CDNA4 playbook, "256^2 8-phase" family; the schedule below is derived in DESIGN.md section 4.1):
+//  * 512 threads = 8 waves as 2(M) x 4(N); a wave owns 128x64 of the tile = 2x2 quadrants of 64x32, i.e. 128
+//    accumulator VGPRs of v_mfma_f32_16x16x32_bf16; ONE workgroup per CU (128 KiB LDS), two waves per SIMD.
+//  * A K tile (64 deep) is staged as FOUR 16 KiB half-tiles cut by USE, not by position:
+//      A-first  = the first 64 rows of each wave-row's 128  (tile rows 0-63, 128-191)
+//      B-first  = the first 32 cols of each wave-col's 64   (tile cols 0-31, 64-95, 128-159, 192-223)
+//      B-second, A-second = the rest.
+//    A K tile is consumed in 4 phases, one accumulator quadrant each: (A0,B0) (A0,B1) (A1,B1) (A1,B0). Phase 0
+//    needs A-first+B-first, phase 1 B-second, phase 2 A-second, phase 3 nothing new - so half-tiles are DMA'd
+//    (global_load_lds_dwordx4, 2 per wave per half-tile) in exactly that order, one per phase, into the OTHER
+//    K-tile buffer, 3-4 phases before their first read. Waits are counted (s_waitcnt vmcnt(4): two half-tiles
+//    stay in flight across every barrier), barriers are raw s_barrier, never __syncthreads (which would drain).
+//  * every phase is  [ds_read operand sub-block | issue DMA | wait] s_barrier [16 MFMA] s_barrier ; the second
+//    wave-row runs one barrier behind the first, so on each SIMD one wave is in its MFMA section while its
+//    partner is in its LDS/DMA section.
+//  * RAW: a half-tile is read one phase after the wait that retires it (all waves wait, then a barrier).
+//    WAR: a slot is re-staged >= 4 phases after its last read. Both hold for the lagging wave-row too.
+//  * persistent: a workgroup walks its work items (tile x K-split) as ONE stream of K tiles, so the DMA for the next
+//    output tile's first K tiles is in flight while the current tile's epilogue stores run.
+#include "gemm_common.h"
+
+using namespace stonk_gemm;
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF_BYTES = 128 * BK * 2;       // 16 KiB
+constexpr int STAGE_BYTES = 4 * HALF_BYTES;    // 64 KiB per K tile
+constexpr int LDS_STAGES = 2 * STAGE_BYTES;    // 128 KiB of K-tile stages
+constexpr int LDS_BYTES = LDS_STAGES + 8 * 4096;  // + a private 4 KiB epilogue slab per wave = 160 KiB
+// slot order inside a stage = DMA / first-use order
+constexpr int SLOT_A0 = 0, SLOT_B0 = 1, SLOT_B1 = 2, SLOT_A1 = 3;
+
+__device__ __forceinline__ void wait_vm4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void barrier() { __builtin_amdgcn_s_barrier(); }
+
+struct Work {
+  int m0, n0;       // tile origin
+  long k_begin;     // element offset of the first K tile
+  int nk;           // K tiles in this work item
+};
+
+template <int OUT_MODE>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  int M = p.M;
+  if (p.m_dev) {
+    const int md = *p.m_dev;
+    M = md < M ? md : M;
+  }
+  const int N = p.N;
+  const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+  int nk_total = p.K / BK;
+  if (p.k_dev) {
+    const int kd = (*p.k_dev + BK - 1) / BK;
+    nk_total = kd < nk_total ? kd : nk_total;
+  }
+  const int nk_per = (nk_total + p.split_k - 1) / p.split_k;
+  const int per_split = ntm * ntn;
+  const int total = per_split * p.split_k;
+  const int G = gridDim.x;
+
+  // work item -> tile; items processed in the same round by the workgroups of one XCD are neighbours
+  auto get_work = [&](int w, Work& o) -> bool {
+    if (w >= total) return false;
+    int idx = w;
+    if ((G & 7) == 0) {
+      const int r = w / G, b = w - r * G;
+      const int cand = r * G + (b & 7) * (G >> 3) + (b >> 3);
+      if ((r + 1) * G <= total) idx = cand;  // full rounds only; the ragged last round keeps natural order
+    }
+    const int ks = idx / per_split;
+    const int tt = idx - ks * per_split;
+    int rt, ct;
+    if (ntm >= ntn) {
+      rt = tt / ntn;
+      ct = tt - rt * ntn;
+    } else {
+      ct = tt / ntm;
+      rt = tt - ct * ntm;
+    }
+    o.m0 = rt * BM;
+    o.n0 = ct * BN;
+    o.k_begin = (long)ks * nk_per * BK;
+    int nk = nk_total - ks * nk_per;
+    o.nk = nk < nk_per ? nk : nk_per;
+    return true;
+  };
+
+  // ---- DMA sources of the prefetch cursor. Nothing per-lane is kept across the loop (a spilled address would be
+  // reloaded behind a compiler-inserted vmcnt(0) and serialise the DMA pipeline): each issue recomputes its two
+  // row addresses from wave-uniform scalars + (lane >> 3), ~10 VALU beside 16 MFMAs.
+  const int l8 = lane >> 3;                                   // row within an 8-row DMA piece
+  const int cofs = ((lane & 7) ^ (l8 & 7)) * 16;              // swizzled source chunk (bytes) for LDS slot (lane & 7)
+  long pk_bytes = 0;  // byte offset (along K) of the K tile the prefetch cursor points at
+  int p_m0 = 0, p_n0 = 0;
+  auto set_sources = [&](const Work& w) {
+    p_m0 = w.m0;
+    p_n0 = w.n0;
+    pk_bytes = w.k_begin * 2;
+  };
+  // issue half-tile `slot` of the K tile at the prefetch cursor into stage `buf`
+  auto issue = [&](int slot, int buf) {
+    char* dst = smem + buf * STAGE_BYTES + slot * HALF_BYTES + wave * 2048;
+    const bool isA = (slot == SLOT_A0 || slot == SLOT_A1);
+    const char* base = (const char*)(isA ? p.A : p.B) + pk_bytes;
+    const long ld2 = (isA ? p.lda : p.ldb) * 2;
+    const int lim = (isA ? M : N) - 1;
+    int l8v = l8, cv = cofs;
+    asm volatile("" : "+v"(l8v), "+v"(cv));  // opaque: keeps the address arithmetic here instead of hoisted + spilled
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // image row r = (wave*2+i)*8 + l8 of the 128-row half-tile:
+      //  A halves: rows 0-63 -> wave-row 0, 64-127 -> wave-row 1 (tile row (r>>6)*128 + (r&63), +64 for A-second)
+      //  B halves: rows 32j..32j+31 -> wave-col j            (tile col (r>>5)*64 + (r&31), +32 for B-second)
+      int row;
+      if (isA) row = p_m0 + (wave >> 2) * 128 + ((wave & 3) * 2 + i) * 8 + (slot == SLOT_A1 ? 64 : 0) + l8v;
+      else row = p_n0 + (wave >> 1) * 64 + ((wave & 1) * 2 + i) * 8 + (slot == SLOT_B1 ? 32 : 0) + l8v;
+      row = row < lim ? row : lim;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + row * ld2 + cv),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment read offsets (bytes) inside a half-tile image
+  const int frag_off = (lane & 15) * 128;
+  const int kc = lane >> 4, swz = lane & 7;
+  const int a_row0 = wr * 64 * 128;   // this wave-row's 64 rows of an A half
+  const int b_row0 = wc * 32 * 128;   // this wave-col's 32 rows of a B half
+
+  f32x4 acc[2][2][4][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  bf16x8 fa[2][4], fb[2][2];  // [k-step][tile]
+  auto read_a = [&](int buf, int slot) {
+    const char* s = smem + buf * STAGE_BYTES + slot * HALF_BYTES + a_row0 + frag_off;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[ks][i] = *(const bf16x8*)(s + i * 2048 + (((ks * 4 + kc) ^ swz) << 4));
+  };
+  auto read_b = [&](int buf, int slot) {
+    const char* s = smem + buf * STAGE_BYTES + slot * HALF_BYTES + b_row0 + frag_off;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[ks][j] = *(const bf16x8*)(s + j * 2048 + (((ks * 4 + kc) ^ swz) << 4));
+  };
+  auto mma = [&](f32x4 (&c)[4][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // swapped operands: D[n][m], so a lane ends up with 4 consecutive output columns of one row
+          c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], c[i][j], 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- epilogue: the tile leaves through a PRIVATE 4 KiB LDS slab per wave (16 rows x 64 cols fp32 per round, XOR
+  // swizzled), so that every global access of the epilogue - output, residual, saved pre-activation - is a full
+  // 16-byte-per-lane row segment (4 lanes = one 128-byte line) instead of 8-byte pieces scattered over 16 rows
+  // (those cost more than the whole K loop at K = 768). Wave-private: no workgroup barrier, the DMA stream of the
+  // next tile keeps running underneath.
+  auto store_tile = [&](const Work& w) {
+    char* ep = smem + LDS_STAGES + wave * 4096;
+    const int flags = p.flags;
+    const int wm = lane & 15, wq = lane >> 4;   // write side: row, 4-column group inside a 16x16 fragment tile
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int ch = b * 8 + j * 4 + wq;  // 16-byte chunk of the 256-byte row
+            *(f32x4*)(ep + wm * 256 + ((ch ^ wm) << 4)) = acc[a][b][i][j] * p.alpha;
+          }
+        __builtin_amdgcn_wave_barrier();
+        const int m = w.m0 + wr * 128 + a * 64 + i * 16;
+        const int n0 = w.n0 + wc * 64;
+        if (OUT_MODE == 2) {
+          // fp32 accumulate: one atomic wave-instruction = 64 consecutive floats of one row (256 contiguous bytes)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float x = *(const float*)(ep + r * 256 + (((lane >> 2) ^ r) << 4) + (lane & 3) * 4);
+            if (m + r < M && n0 + lane < N) atomicAdd((float*)p.C + (long)(m + r) * p.ldc + n0 + lane, x);
+          }
+        } else {
+          // read side: 8 lanes x 8 columns = one full 128-byte (bf16) output line per row, 8 rows per instruction
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int row = h * 8 + (lane >> 3), c8 = lane & 7;
+            const f32x4 q0 = *(const f32x4*)(ep + row * 256 + (((2 * c8) ^ row) << 4));
+            const f32x4 q1 = *(const f32x4*)(ep + row * 256 + (((2 * c8 + 1) ^ row) << 4));
+            const int mm = m + row, n = n0 + c8 * 8;
+            if (mm < M && n < N) {
+              float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+              epilogue8(v, p, flags, mm, n);
+              if (OUT_MODE == 0) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+                *(bf16x8*)((bf16*)p.C + (long)mm * p.ldc + n) = o;
+              } else {
+                float* dst = (float*)p.C + (long)mm * p.ldc + n;
+                *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+                *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+  };
+
+  // ------------------------------------------------------------------ stream of K tiles
+  Work cw, pw;            // compute / prefetch work items
+  int cwi = blockIdx.x;   // their indices
+  if (!get_work(cwi, cw) ) return;                    // uniform: whole workgroup leaves together
+  while (cw.nk <= 0) {                                // (k_dev may leave a K-split empty)
+    cwi += G;
+    if (!get_work(cwi, cw)) return;
+  }
+  int pwi = cwi;
+  pw = cw;
+  int pk = 0;             // K tile (within pw) the prefetch cursor points at
+  bool p_valid = true;
+  set_sources(pw);
+  // advance the prefetch cursor by one K tile (after its 4 half-tiles have been issued)
+  auto advance_prefetch = [&]() {
+    ++pk;
+    pk_bytes += BK * 2;
+    if (pk >= pw.nk) {
+      do {
+        pwi += G;
+        p_valid = get_work(pwi, pw);
+      } while (p_valid && pw.nk <= 0);
+      pk = 0;
+      if (p_valid) set_sources(pw);
+    }
+  };
+
+  // prologue: the whole first K tile
+  issue(SLOT_A0, 0);
+  issue(SLOT_B0, 0);
+  issue(SLOT_B1, 0);
+  issue(SLOT_A1, 0);
+  advance_prefetch();
+  wait_vm4();   // A-first, B-first landed (this wave's part)
+  barrier();
+  if (wr == 1) barrier();   // second wave-row runs one barrier behind
+  zero_acc();
+
+  int buf = 0;    // stage holding the compute K tile
+  // `fresh`: first K tile after a tile boundary. There every DMA issued so far has already been waited for (before
+  // the epilogue stores were issued), so phases 0-2 need no wait - and must not have one: vmcnt counts in order, a
+  // wait there would sit behind the 16 epilogue stores of this wave. Their drain hides under these three phases.
+  bool fresh = false;
+  for (;;) {      // one output tile (work item) per iteration; the DMA stream runs across iterations
+    for (int ck = 0; ck < cw.nk; ++ck) {
+      const int nb = buf ^ 1;
+      // ---------------- phase 0: quadrant (A0, B0)
+      read_a(buf, SLOT_A0);
+      read_b(buf, SLOT_B0);
+      if (p_valid) issue(SLOT_A0, nb);
+      if (!fresh) { if (p_valid) wait_vm4(); else wait_vm0(); }                // retires B-second of this K tile
+      barrier();
+      wait_lgkm0();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(acc[0][0]);
+      barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- phase 1: quadrant (A0, B1)
+      read_b(buf, SLOT_B1);
+      if (p_valid) issue(SLOT_B0, nb);
+      if (!fresh) { if (p_valid) wait_vm4(); else wait_vm0(); }                // retires A-second of this K tile
+      barrier();
+      wait_lgkm0();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(acc[0][1]);
+      barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- phase 2: quadrant (A1, B1)
+      read_a(buf, SLOT_A1);   // B1 fragments are still in registers
+      if (p_valid) issue(SLOT_B1, nb);
+      barrier();
+      wait_lgkm0();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(acc[1][1]);
+      barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- phase 3: quadrant (A1, B0)
+      read_b(buf, SLOT_B0);   // re-read (16 VGPRs cheaper than keeping B0 live through all four phases)
+      if (p_valid) issue(SLOT_A1, nb);
+      const bool issued = p_valid;
+      if (issued) { wait_vm4(); } else { wait_vm0(); }                          // retires A-first, B-first of the next K tile
+      barrier();
+      wait_lgkm0();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(acc[1][0]);
+      barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (issued) advance_prefetch();
+      buf = nb;
+      fresh = false;
+    }
+    wait_vm0();   // B-second / A-second of the next K tile: land them BEFORE the stores enter the vmcnt queue
+    store_tile(cw);
+    fresh = true;
+    bool more;
+    do {
+      cwi += G;
+      more = get_work(cwi, cw);
+    } while (more && cw.nk <= 0);
+    if (!more) break;
+    zero_acc();
+  }
+  if (wr == 0) barrier();   // balance the stagger barrier
+}
+
+}  // namespace
+
+int stonk_gemm256_launch(const GemmArgs& a, int out_mode, hipStream_t st) {
+  static bool attr_done[3] = {false, false, false};
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
+    n_cu = prop.multiProcessorCount;
+  }
+  const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.split_k;
+  const int grid = (int)(tiles < n_cu ? tiles : n_cu);
+#define LAUNCH256(MODE)                                                                                         \
+  do {                                                                                                          \
+    if (!attr_done[MODE]) {                                                                                     \
+      (void)hipFuncSetAttribute((const void*)gemm256_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                LDS_BYTES);                                                                     \
+      attr_done[MODE] = true;                                                                                   \
+    }                                                                                                           \
+    hipLaunchKernelGGL((gemm256_kernel<MODE>), dim3(grid), dim3(512), LDS_BYTES, st, a);                        \
+  } while (0)
+  if (out_mode == 0) LAUNCH256(0);
+  else if (out_mode == 1) LAUNCH256(1);
+  else LAUNCH256(2);
+#undef LAUNCH256
+  return stonk_launch_status();
+}

@@ -13,8 +13,12 @@
 // Operand tiles are staged global->LDS with 16-byte LDS-DMA (global_load_lds_dwordx4), double buffered;
 // the LDS image is lane-linear, the XOR swizzle (chunk ^ (row & 7)) is applied on the per-lane SOURCE
 // address and again on the ds_read_b128 fragment reads (conflict-free for 128-byte rows).
-#include "common.h"
-#include "stonk_flags.h"
+#include "gemm_common.h"
+
+using namespace stonk_gemm;
+
+// defined in gemm256.hip
+int stonk_gemm256_launch(const GemmArgs& a, int out_mode, hipStream_t st);
 
 namespace {
 
@@ -22,33 +26,6 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
 constexpr int GEMM_LDS = 2 * STAGE_BYTES;      // double buffered: 64 KiB
-
-struct GemmArgs {
-  const bf16* A;
-  const bf16* B;
-  void* C;
-  const float* bias;
-  const bf16* resid;
-  bf16* aux;
-  const int* m_dev;
-  const int* k_dev;
-  long lda, ldb, ldc, ldr, ldaux;
-  int M, N, K;
-  int flags;
-  float alpha;
-  int split_k;
-  uint32_t drop_thr24;
-  float drop_scale;
-  uint32_t seed;
-};
-
-// blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of tiles so
-// neighbouring tiles (same A row panel / same B column panel) hit the same L2. Bijective for any n.
-__device__ __forceinline__ int xcd_remap(int b, int n) {
-  const int q = n >> 3, r = n & 7, x = b & 7;
-  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-  return base + (b >> 3);
-}
 
 template <int OUT_MODE, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
@@ -216,32 +193,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-          f32x4 v = acc[i][j] * p.alpha;
-          if (flags & STONK_EPI_BIAS) v += *(const f32x4*)(p.bias + n);
-          if (flags & STONK_EPI_SAVE_PREACT) {
-            bf16x4 u = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-            *(bf16x4*)(p.aux + (long)m * p.ldaux + n) = u;
-          }
-          if (flags & STONK_EPI_GELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-          }
-          if (flags & STONK_EPI_GELU_BWD) {
-            const bf16x4 u = *(const bf16x4*)(p.aux + (long)m * p.ldaux + n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)u[r]);
-          }
-          if (flags & STONK_EPI_DROPOUT) {
-            const uint32_t e = (uint32_t)((long)m * p.N + n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              v[r] = stonk_keep(e + r, p.seed, p.drop_thr24) ? v[r] * p.drop_scale : 0.f;
-          }
-          if (flags & STONK_EPI_RESID) {
-            const bf16x4 rr = *(const bf16x4*)(p.resid + (long)m * p.ldr + n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-          }
+          const f32x4 v = epilogue4(acc[i][j] * p.alpha, p, flags, m, n);
           if (OUT_MODE == 0) {
             bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
             *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = o;
@@ -296,11 +248,21 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   a.drop_scale = 1.0f / (1.0f - drop_p);
   a.seed = seed;
 
+  hipStream_t st = (hipStream_t)stream;
+  // large launches go to the persistent 256x256 kernel (gemm256.hip); small ones keep the 128x128 tiles
+  // measured on MI355X (tools/bench_kernels.py): the 256x256 kernel wins for wide outputs (N >= 2304, where its
+  // halved operand traffic per flop outweighs one-workgroup-per-CU epilogues); N = 768 quantises badly (3 column tiles)
+  const bool big = M >= 1024 && N >= 1536 && out_mode != STONK_EPI_OUT_F32_ATOMIC;
+  // its epilogue moves 16-byte row segments: strides of every side operand must keep them aligned
+  const bool v2_ok = ldc % 8 == 0 && (!(flags & STONK_EPI_RESID) || (ldr % 8 == 0 && (uintptr_t)resid % 16 == 0)) &&
+                     (!(flags & (STONK_EPI_SAVE_PREACT | STONK_EPI_GELU_BWD)) ||
+                      (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0));
+  if (v2_ok && !(flags & (STONK_EPI_DEBUG_V1 | STONK_EPI_DEBUG_REGSTAGE)) && (big || (flags & STONK_EPI_DEBUG_V2)))
+    return stonk_gemm256_launch(a, out_mode, st);
   const long tiles = (long)((M + BM - 1) / BM) * (N / BN) * split_k;
   // with a device-side row count the grid is capped and blocks walk the tiles that exist at run time
   const long cap = m_dev ? 4096 : tiles;
   const int grid = (int)(tiles < cap ? tiles : cap);
-  hipStream_t st = (hipStream_t)stream;
   const bool glds = !(flags & STONK_EPI_DEBUG_REGSTAGE);
   switch (out_mode) {
     case STONK_EPI_OUT_BF16: return glds ? launch<0, true>(a, grid, st) : launch<0, false>(a, grid, st);

@@ -1,0 +1,104 @@
+// Argument block and helpers shared by the two bf16 GEMM kernels (gemm_bf16.hip: 128x128 tiles, gemm256.hip:
+// persistent 256x256 tiles). See stonk_gemm_nt_bf16 in include/stonk_hip.h for the meaning of each field.
+#pragma once
+#include "common.h"
+#include "stonk_flags.h"
+
+namespace stonk_gemm {
+
+struct GemmArgs {
+  const bf16* A;
+  const bf16* B;
+  void* C;
+  const float* bias;
+  const bf16* resid;
+  bf16* aux;
+  const int* m_dev;
+  const int* k_dev;
+  long lda, ldb, ldc, ldr, ldaux;
+  int M, N, K;
+  int flags;
+  float alpha;
+  int split_k;
+  uint32_t drop_thr24;
+  float drop_scale;
+  uint32_t seed;
+};
+
+// blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of tiles so
+// neighbouring tiles (same A row panel / same B column panel) hit the same L2. Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (b >> 3);
+}
+
+
+// Fused epilogue on 4 consecutive output columns n..n+3 of row m (values already scaled by alpha).
+__device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& p, int flags, int m, int n) {
+  if (flags & STONK_EPI_BIAS) v += *(const f32x4*)(p.bias + n);
+  if (flags & STONK_EPI_SAVE_PREACT) {
+    bf16x4 u = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *(bf16x4*)(p.aux + (long)m * p.ldaux + n) = u;
+  }
+  if (flags & STONK_EPI_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+  }
+  if (flags & STONK_EPI_GELU_BWD) {
+    const bf16x4 u = *(const bf16x4*)(p.aux + (long)m * p.ldaux + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)u[r]);
+  }
+  if (flags & STONK_EPI_DROPOUT) {
+    const uint32_t e = (uint32_t)((long)m * p.N + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = stonk_keep(e + r, p.seed, p.drop_thr24) ? v[r] * p.drop_scale : 0.f;
+  }
+  if (flags & STONK_EPI_RESID) {
+    const bf16x4 rr = *(const bf16x4*)(p.resid + (long)m * p.ldr + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+  }
+  return v;
+}
+
+// Fused epilogue on 8 consecutive output columns n..n+7 of row m (fp32 values already scaled by alpha): every side
+// operand (bias, saved pre-activation, residual) is read / written as one 16- or 32-byte vector.
+__device__ __forceinline__ void epilogue8(float (&v)[8], const GemmArgs& p, int flags, int m, int n) {
+  if (flags & STONK_EPI_BIAS) {
+    const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] += b0[r];
+      v[4 + r] += b1[r];
+    }
+  }
+  if (flags & STONK_EPI_SAVE_PREACT) {
+    bf16x8 u;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) u[r] = (bf16)v[r];
+    *(bf16x8*)(p.aux + (long)m * p.ldaux + n) = u;
+  }
+  if (flags & STONK_EPI_GELU) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = gelu_erf(v[r]);
+  }
+  if (flags & STONK_EPI_GELU_BWD) {
+    const bf16x8 u = *(const bf16x8*)(p.aux + (long)m * p.ldaux + n);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad((float)u[r]);
+  }
+  if (flags & STONK_EPI_DROPOUT) {
+    const uint32_t e = (uint32_t)((long)m * p.N + n);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = stonk_keep(e + r, p.seed, p.drop_thr24) ? v[r] * p.drop_scale : 0.f;
+  }
+  if (flags & STONK_EPI_RESID) {
+    const bf16x8 rr = *(const bf16x8*)(p.resid + (long)m * p.ldr + n);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] += (float)rr[r];
+  }
+}
+
+}  // namespace stonk_gemm

@@ -11,7 +11,9 @@
 #define STONK_EPI_SAVE_PREACT (1 << 5)  /* aux[m][n] (bf16) = value before the activation */
 #define STONK_EPI_GELU_BWD (1 << 6)     /* result *= gelu'(aux[m][n]) */
 #define STONK_EPI_DROPOUT (1 << 7)      /* inverted dropout (drop_p, seed) before the residual add */
-#define STONK_EPI_DEBUG_REGSTAGE (1 << 16) /* A/B test: register staging instead of LDS-DMA */
+#define STONK_EPI_DEBUG_REGSTAGE (1 << 16) /* A/B test: register staging instead of LDS-DMA (128x128 kernel) */
+#define STONK_EPI_DEBUG_V1 (1 << 17)       /* force the 128x128 two-barrier kernel */
+#define STONK_EPI_DEBUG_V2 (1 << 18)       /* force the persistent 256x256 kernel */
 // --- stonk_layernorm_* `flags` ---
 #define STONK_LN_DROPOUT (1 << 0)
 // --- stonk_small_linear_* `act` ---

@@ -24,12 +24,16 @@ def _rand(shape, scale=1.0, seed=0):
     return (torch.randn(shape, device="cuda", generator=g) * scale).to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("regstage", [False, True])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (1000, 768, 3072), (77, 2304, 768)])
-def test_gemm_plain_bf16_and_f32(hip, M, N, K, regstage):
+KERNELS = {"v1": 1 << 17, "v1_regstage": 1 << 16, "v2_256": 1 << 18, "auto": 0}
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (1000, 768, 3072), (77, 2304, 768),
+                                   (2000, 1152, 1024), (4096, 29056, 128)])
+def test_gemm_plain_bf16_and_f32(hip, M, N, K, kernel):
     A, B = _rand((M, K), seed=1), _rand((N, K), seed=2)
     ref = A.float() @ B.float().t()
-    dbg = hip.EPI_DEBUG_REGSTAGE if regstage else 0
+    dbg = KERNELS[kernel]
     out32 = _gemm(hip, A, B, torch.float32, flags=hip.EPI_OUT_F32 | dbg)
     torch.cuda.synchronize()
     err = (out32 - ref).abs().max().item()
@@ -47,7 +51,8 @@ def test_gemm_asymmetric_identity(hip):
     torch.testing.assert_close(out, B.float().t().contiguous(), rtol=0, atol=0)
 
 
-def test_gemm_epilogues(hip):
+@pytest.mark.parametrize("dbg", [1 << 17, 1 << 18])
+def test_gemm_epilogues(hip, dbg):
     M, N, K = 300, 256, 192
     A, B = _rand((M, K), 0.5, 3), _rand((N, K), 0.5, 4)
     bias = torch.randn(N, device="cuda")
@@ -55,26 +60,53 @@ def test_gemm_epilogues(hip):
     pre = A.float() @ B.float().t() + bias
     # bias + gelu + saved pre-activation
     aux = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
-    out = _gemm(hip, A, B, flags=hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT, bias=bias, aux=aux)
+    out = _gemm(hip, A, B, flags=dbg | hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT, bias=bias, aux=aux)
     torch.testing.assert_close(aux.float(), pre, rtol=1e-2, atol=2e-2)
     torch.testing.assert_close(out.float(), torch.nn.functional.gelu(pre), rtol=1e-2, atol=2e-2)
     # bias + residual
-    out = _gemm(hip, A, B, flags=hip.EPI_BIAS | hip.EPI_RESID, bias=bias, resid=resid)
+    out = _gemm(hip, A, B, flags=dbg | hip.EPI_BIAS | hip.EPI_RESID, bias=bias, resid=resid)
     torch.testing.assert_close(out.float(), pre + resid.float(), rtol=1e-2, atol=3e-2)
     # gelu backward: result * gelu'(aux)
     u = _rand((M, N), 1.0, 6)
-    out = _gemm(hip, A, B, flags=hip.EPI_GELU_BWD, aux=u)
+    out = _gemm(hip, A, B, flags=dbg | hip.EPI_GELU_BWD, aux=u)
     uf = u.float().requires_grad_(True)
     (gp,) = torch.autograd.grad(torch.nn.functional.gelu(uf).sum(), uf)
     torch.testing.assert_close(out.float(), (A.float() @ B.float().t()) * gp, rtol=1e-2, atol=3e-2)
 
 
-def test_gemm_splitk_atomic_accumulates(hip):
-    M, N, K = 256, 128, 2048
+@pytest.mark.parametrize("dbg,M,N,K,sk", [(1 << 17, 256, 128, 2048, 8), (1 << 18, 768, 768, 8192, 7),
+                                          (1 << 18, 300, 256, 4096, 32), (0, 3072, 768, 32768, 8)])
+def test_gemm_splitk_atomic_accumulates(hip, dbg, M, N, K, sk):
     A, B = _rand((M, K), 0.3, 7), _rand((N, K), 0.3, 8)
     C = torch.ones(M, N, device="cuda")
-    _gemm(hip, A, B, flags=hip.EPI_OUT_F32_ATOMIC, split_k=8, C=C)
-    torch.testing.assert_close(C, 1.0 + A.float() @ B.float().t(), rtol=1e-4, atol=1e-3)
+    _gemm(hip, A, B, flags=dbg | hip.EPI_OUT_F32_ATOMIC, split_k=sk, C=C)
+    torch.testing.assert_close(C, 1.0 + A.float() @ B.float().t(), rtol=1e-4, atol=2e-3 * (K / 2048) ** 0.5)
+
+
+def test_gemm256_device_counts_and_races(hip):
+    """Persistent 256x256 kernel: device-side M and K, many work items per workgroup, repeated launches must be
+    bit-identical (an LDS-DMA race would show up as rare differing tiles)."""
+    M, N, K = 16384, 768, 1024
+    A, B = _rand((M, K), 0.5, 21), _rand((N, K), 0.5, 22)
+    m_dev = torch.tensor([2432 - 5], device="cuda", dtype=torch.int32)
+    C = torch.full((M, N), -7.0, device="cuda")
+    _gemm(hip, A, B, flags=hip.EPI_DEBUG_V2 | hip.EPI_OUT_F32, C=C, m_dev=m_dev)
+    ref = A[:2427].float() @ B.float().t()
+    torch.testing.assert_close(C[:2427], ref, rtol=1e-4, atol=2e-3)
+    assert (C[2427:] == -7.0).all()
+    # device-side contraction length (label-sparse wgrad): K tiles past ceil(k/64) are skipped
+    k_dev = torch.tensor([300], device="cuda", dtype=torch.int32)
+    A2, B2 = _rand((1024, 4096), 0.5, 23), _rand((768, 4096), 0.5, 24)
+    A2[:, 300:] = 0  # what the zero-filling transpose guarantees up to the 64 round-up
+    C2 = torch.zeros(1024, 768, device="cuda")
+    _gemm(hip, A2, B2, flags=hip.EPI_DEBUG_V2 | hip.EPI_OUT_F32_ATOMIC, split_k=4, C=C2, k_dev=k_dev)
+    torch.testing.assert_close(C2, A2[:, :320].float() @ B2[:, :320].float().t(), rtol=1e-4, atol=2e-3)
+    # race screen
+    A3, B3 = _rand((8192, 768), 1.0, 25), _rand((3072, 768), 0.05, 26)
+    first = _gemm(hip, A3, B3, flags=hip.EPI_DEBUG_V2)
+    torch.testing.assert_close(first.float(), A3.float() @ B3.float().t(), rtol=2e-2, atol=2e-2)
+    for _ in range(20):
+        assert torch.equal(_gemm(hip, A3, B3, flags=hip.EPI_DEBUG_V2), first)
 
 
 def test_gemm_device_row_count_and_dropout(hip):

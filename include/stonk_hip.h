@@ -41,6 +41,12 @@ int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, v
                        float alpha, int split_k, const int* m_dev, const int* k_dev, float drop_p, uint32_t seed,
                        void* stream);
 
+/* Weight / bias gradient straight from row-major activations: dW[M',N'] += alpha * dY[T,M']^T . X[T,N'],
+ * db[M'] += alpha * colsum(dY) (nullable). M', N' % 128 == 0; rows of dY / X in [k, roundup64(k)) must read as zero when
+ * the token count k (<= K) comes from k_dev. Autograd's weight/bias gradients of every nn.Linear on the path. */
+int stonk_gemm_tn_bf16(const void* dY, int64_t lda, const void* X, int64_t ldb, float* dW, int64_t ldc, float* dbias,
+                       int M, int N, int K, float alpha, int split_k, const int* k_dev, void* stream);
+
 /* y = dropout(LayerNorm(x)); x,y bf16 [rows,H]; gamma/beta fp32; mean/rstd fp32 [rows] saved for backward.
  * Replaces nn.LayerNorm(eps=1e-12) + nn.Dropout at hf:modeling_bert.py:106-107, :291-292, :349-350, :479. */
 int stonk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
@@ -108,10 +114,11 @@ int stonk_scatter_rows_f32_to_bf16(const float* src, int64_t ld_src, const int* 
                                    int64_t ld_dst, int cols, void* stream);
 
 /* Per labelled row: loss_sum += logsumexp(logits[row,:ncols]) - logits[row,target];
- * dlogits (bf16, nullable) = (softmax - onehot) * grad_scale / count. Bit 3 of *err_flag: target out of range. */
+ * dlogits (bf16, nullable, cap_rows rows allocated) = (softmax - onehot) * grad_scale / count, rows
+ * [count, roundup64(count)) zeroed. Bit 3 of *err_flag: target out of range. */
 int stonk_softmax_xent_fwd_bwd(const float* logits, int64_t ld, int ncols, int npad, const int* targets,
                                const int* count_dev, float* loss_sum, void* dlogits, int64_t ld_d, float grad_scale,
-                               int* err_flag, void* stream);
+                               int cap_rows, int* err_flag, void* stream);
 /* NSP loss (ref:stonkgs_model.py:241-243): loss_sum_cnt[0] += sum, [1] += number of labels. */
 int stonk_nsp_xent_fwd_bwd(const float* logits, const int64_t* labels, int B, int C, float* loss_sum_cnt, float* dlogits,
                            float grad_scale, int* err_flag, void* stream);

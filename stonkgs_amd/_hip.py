@@ -35,6 +35,7 @@ _vp, _i32, _i64, _f32, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uin
 _SIGNATURES = {
     "stonk_gemm_nt_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i64,
                            _f32, _i32, _vp, _vp, _f32, _u32, _vp],
+    "stonk_gemm_tn_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp],
     "stonk_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _f32, _u32, _vp],
     "stonk_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _u32, _f32, _u32,
                             _vp],
@@ -53,7 +54,7 @@ _SIGNATURES = {
     "stonk_gather_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _vp],
     "stonk_scatter_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp],
     "stonk_scatter_rows_f32_to_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp],
-    "stonk_softmax_xent_fwd_bwd": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _f32, _vp, _vp],
+    "stonk_softmax_xent_fwd_bwd": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _f32, _i32, _vp, _vp],
     "stonk_nsp_xent_fwd_bwd": [_vp, _vp, _i32, _i32, _vp, _vp, _f32, _vp, _vp],
     "stonk_loss_finalize": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "stonk_small_linear_fwd": [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],

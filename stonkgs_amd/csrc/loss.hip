@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void scatter_rows_f32_kernel(const float* __re
 __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits, long ld, int ncols, int npad,
                                                            const int* __restrict__ targets, const int* __restrict__ count,
                                                            float* __restrict__ loss_sum, bf16* __restrict__ dlogits,
-                                                           long ld_d, float gscale, int* __restrict__ err) {
+                                                           long ld_d, float gscale, int* __restrict__ err,
+                                                           int cap_rows) {
   __shared__ float red_m[4], red_s[4];
   const int cnt = *count;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -186,6 +187,17 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
       }
     }
     __syncthreads();
+  }
+  // rows [count, roundup64(count)) are read (as zeros) by the 64-token K step of the weight-gradient GEMM
+  if (dlogits) {
+    const int lim = (cnt + 63) / 64 * 64;
+    for (int row = cnt + blockIdx.x; row < lim && row < cap_rows; row += gridDim.x) {
+      bf16* d = dlogits + (long)row * ld_d;
+      bf16x8 z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+      for (int i = t; i < (npad >> 3); i += 256) *(bf16x8*)(d + i * 8) = z;
+    }
   }
 }
 
@@ -273,12 +285,12 @@ extern "C" int stonk_scatter_rows_f32_to_bf16(const float* src, int64_t ld_src, 
 
 extern "C" int stonk_softmax_xent_fwd_bwd(const float* logits, int64_t ld, int ncols, int npad, const int* targets,
                                           const int* count_dev, float* loss_sum, void* dlogits, int64_t ld_d,
-                                          float grad_scale, int* err_flag, void* stream) {
-  STONK_CHECK_ARG(logits && targets && count_dev && loss_sum && err_flag, STONK_EINVAL);
+                                          float grad_scale, int cap_rows, int* err_flag, void* stream) {
+  STONK_CHECK_ARG(logits && targets && count_dev && loss_sum && err_flag && cap_rows >= 0, STONK_EINVAL);
   STONK_CHECK_ARG(ncols > 0 && npad >= ncols && npad % 8 == 0 && ld >= npad && ld % 4 == 0, STONK_ESHAPE);
   STONK_CHECK_ARG(!dlogits || (ld_d >= npad && ld_d % 8 == 0), STONK_ESHAPE);
   hipLaunchKernelGGL(softmax_xent_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, ncols, npad,
-                     targets, count_dev, loss_sum, (bf16*)dlogits, (long)ld_d, grad_scale, err_flag);
+                     targets, count_dev, loss_sum, (bf16*)dlogits, (long)ld_d, grad_scale, err_flag, cap_rows);
   return stonk_launch_status();
 }
 

@@ -102,14 +102,23 @@ class Engine:
 
     @staticmethod
     def _split_k(M, N, K) -> int:
+        # 128x128 tiles, two workgroups co-resident per CU = 512 slots on 256 CUs: the sweep in tools/sweep_wgrad.py
+        # is fastest when tiles x split fills ONE co-resident wave without a tail (432-480 workgroups)
         tiles = ((M + 127) // 128) * (N // 128)
-        s = max(1, min(16, (640 + tiles - 1) // tiles, K // 64))
-        return s
+        return max(1, min(32, 480 // tiles, K // 64))
 
-    def wgrad(self, dyT, xT, dW, M_out, N_in, K, k_dev=None, alpha=1.0):
-        """dW[M_out, N_in] += dyT[M_out, K] . xT[N_in, K]^T   (fp32 atomics, split-K)."""
-        self.gemm(dyT, xT, dW, M_out, N_in, K, flags=hip.EPI_OUT_F32_ATOMIC, split_k=self._split_k(M_out, N_in, K),
-                  k_dev=k_dev, alpha=alpha)
+    def wgrad(self, dy, x, dW, db, M_out, N_in, T, k_dev=None, alpha=1.0):
+        """dW[M_out, N_in] += dy[T, M_out]^T . x[T, N_in];  db[M_out] += colsum(dy)   (fp32 atomics, split-K)."""
+        timed = self.gemm_timer is not None
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        hip.call("stonk_gemm_tn_bf16", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(),
+                 dW.stride(0), hip.ptr(db), M_out, N_in, T, alpha, self._split_k(M_out, N_in, T), hip.ptr(k_dev),
+                 hip.stream_ptr())
+        if timed:
+            e1.record()
+            self.gemm_timer.records.append((e0, e1, M_out, N_in, T, None, k_dev))
 
     def transpose(self, x, rows, cols, name, colsum=None, rows_dev=None):
         rpad = (rows + 63) // 64 * 64
@@ -206,15 +215,12 @@ class Engine:
         if df is None:
             df = ds2
         # ---- FFN down: wgrad, bias grad, dgrad fused with GELU'
-        dfT = self.transpose(df, T, H, "b.tA_H", colsum=g_(prefix + ".output.dense.bias"))
-        gT = self.transpose(sv["g"], T, I, "b.tB_I")
-        self.wgrad(dfT, gT, g_(prefix + ".output.dense.weight"), H, I, T)
+        self.wgrad(df, sv["g"], g_(prefix + ".output.dense.weight"), g_(prefix + ".output.dense.bias"), H, I, T)
         du = self.buf("b.du", (T, I))
         self.gemm(df, wt[prefix + ".output.dense.weight"], du, T, I, H, flags=hip.EPI_GELU_BWD, aux=sv["u"])
         # ---- FFN up
-        duT = self.transpose(du, T, I, "b.tA_I", colsum=g_(prefix + ".intermediate.dense.bias"))
-        h1T = self.transpose(sv["h1"], T, H, "b.tB_H")
-        self.wgrad(duT, h1T, g_(prefix + ".intermediate.dense.weight"), I, H, T)
+        self.wgrad(du, sv["h1"], g_(prefix + ".intermediate.dense.weight"), g_(prefix + ".intermediate.dense.bias"), I, H,
+                   T)
         dh1 = self.buf("b.dh1", (T, H))
         self.gemm(du, wt[prefix + ".intermediate.dense.weight"], dh1, T, H, I, flags=hip.EPI_RESID, resid=ds2)
         # ---- LN1 backward
@@ -228,9 +234,8 @@ class Engine:
         if da is None:
             da = ds1
         # ---- attention output projection
-        daT = self.transpose(da, T, H, "b.tA_H", colsum=g_(prefix + ".attention.output.dense.bias"))
-        ctxT = self.transpose(sv["ctx"], T, H, "b.tB_H")
-        self.wgrad(daT, ctxT, g_(prefix + ".attention.output.dense.weight"), H, H, T)
+        self.wgrad(da, sv["ctx"], g_(prefix + ".attention.output.dense.weight"),
+                   g_(prefix + ".attention.output.dense.bias"), H, H, T)
         dctx = self.buf("b.dctx", (T, H))
         self.gemm(da, wt[prefix + ".attention.output.dense.weight"], dctx, T, H, H)
         # ---- attention core
@@ -242,9 +247,8 @@ class Engine:
                  dqkv.data_ptr(), dqkv.data_ptr() + 2 * H, 3 * H, dqkv.data_ptr() + 4 * H, B, NH, seq, 64,
                  1.0 / math.sqrt(64.0), p_att, self.seed(lidx, 1), st)
         # ---- QKV projection
-        dqkvT = self.transpose(dqkv, T, 3 * H, "b.tA_3H", colsum=g_(prefix + ".attention.self.qkv.bias"))
-        xT = self.transpose(sv["x"], T, H, "b.tB_H")
-        self.wgrad(dqkvT, xT, g_(prefix + ".attention.self.qkv.weight"), 3 * H, H, T)
+        self.wgrad(dqkv, sv["x"], g_(prefix + ".attention.self.qkv.weight"), g_(prefix + ".attention.self.qkv.bias"),
+                   3 * H, H, T)
         dx = self.buf(f"b.dx{lidx & 1}", (T, H))
         self.gemm(dqkv, wt[prefix + ".attention.self.qkv.weight"], dx, T, H, 3 * H, flags=hip.EPI_RESID, resid=ds1)
         return dx
@@ -352,7 +356,7 @@ class Engine:
                 self.gemm(hs, w(wname), logits, cap, npad, H, flags=hip.EPI_OUT_F32, m_dev=cnt)
                 dl = self.buf(f"l.{nm}.dl", (cap, npad)) if need_backward else None
                 hip.call("stonk_softmax_xent_fwd_bwd", logits.data_ptr(), npad, N, npad, tg.data_ptr(), cnt.data_ptr(),
-                         acc[hi:hi + 1].data_ptr(), hip.ptr(dl), npad, 1.0, self.err.data_ptr(), st)
+                         acc[hi:hi + 1].data_ptr(), hip.ptr(dl), npad, 1.0, cap, self.err.data_ptr(), st)
                 save[nm] = dict(rows=rows, cnt=cnt, hs=hs, dl=dl)
             dnsp = self.buf("l.dnsp", (B, 2), F32) if need_backward else None
             hip.call("stonk_nsp_xent_fwd_bwd", nsp.data_ptr(), nsp_labels.data_ptr(), B, 2, acc[2:4].data_ptr(),
@@ -415,10 +419,7 @@ class Engine:
                       split_k=max(1, min(16, npad // 2048)), m_dev=h["cnt"], alpha=gscale)
             hip.call("stonk_scatter_rows_f32_to_bf16", dhs.data_ptr(), H, h["rows"].data_ptr(), h["cnt"].data_ptr(),
                      dt.data_ptr(), H, H, st)
-            dlT = self.transpose(h["dl"], cap, npad, "b.dlT", rows_dev=h["cnt"])
-            hsT = self.transpose(h["hs"], cap, H, "b.hsT", rows_dev=h["cnt"])
-            self.gemm(dlT, hsT, g_(wname, padded=True), npad, H, cap if cap % 64 == 0 else (cap + 63) // 64 * 64,
-                      flags=hip.EPI_OUT_F32_ATOMIC, k_dev=h["cnt"], alpha=gscale)
+            self.wgrad(h["dl"], h["hs"], g_(wname, padded=True), None, npad, H, cap, k_dev=h["cnt"], alpha=gscale)
             notify(wname)
         # ---- head transform backward
         dgt = self.buf("b.dgt", (T, H))
@@ -428,9 +429,8 @@ class Engine:
                  g_("cls.predictions.transform.LayerNorm.bias").data_ptr(), T, H, 0, 0.0, 0, 0.0, 0, st)
         dut = self.buf("b.dut", (T, H))
         hip.call("stonk_gelu_bwd_bf16", dgt.data_ptr(), sv["ut"].data_ptr(), dut.data_ptr(), T * H, st)
-        dutT = self.transpose(dut, T, H, "b.tA_H", colsum=g_("cls.predictions.transform.dense.bias"))
-        seqT = self.transpose(sv["seq_out"], T, H, "b.tB_H")
-        self.wgrad(dutT, seqT, g_("cls.predictions.transform.dense.weight"), H, H, T)
+        self.wgrad(dut, sv["seq_out"], g_("cls.predictions.transform.dense.weight"),
+                   g_("cls.predictions.transform.dense.bias"), H, H, T)
         dseq = self.buf("b.dseq", (T, H))
         self.gemm(dut, wt["cls.predictions.transform.dense.weight"], dseq, T, H, H)
         # ---- NSP + pooler (fp32), pooler gradient lands on position 0 of d(sequence_output)

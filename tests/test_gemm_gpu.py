@@ -132,3 +132,39 @@ def test_gemm_bad_arguments(hip):
     A, B = _rand((128, 64)), _rand((100, 64))
     with pytest.raises(hip.StonkHipError):
         _gemm(hip, A, B)  # N not a multiple of 128
+
+
+@pytest.mark.parametrize("T,Mo,No,sk", [(64, 128, 128, 1), (4096, 768, 768, 12), (8192, 2304, 768, 4), (2048, 768, 3072, 3),
+                                        (640, 29056, 128, 1)])
+def test_gemm_tn_weight_and_bias_gradient(hip, T, Mo, No, sk):
+    """dW += dY^T X and db += colsum(dY) straight from row-major [token][feature] operands (transposed LDS reads)."""
+    dY, X = _rand((T, Mo), 0.5, 31), _rand((T, No), 0.5, 32)
+    dW = torch.full((Mo, No), 0.25, device="cuda")
+    db = torch.full((Mo,), -1.0, device="cuda")
+    hip.call("stonk_gemm_tn_bf16", hip.ptr(dY), Mo, hip.ptr(X), No, hip.ptr(dW), No, hip.ptr(db), Mo, No, T, 0.5, sk, 0,
+             hip.stream_ptr())
+    ref = 0.25 + 0.5 * (dY.float().t() @ X.float())
+    torch.testing.assert_close(dW, ref, rtol=1e-4, atol=2e-3 * (T / 2048) ** 0.5)
+    torch.testing.assert_close(db, -1.0 + 0.5 * dY.float().sum(0), rtol=1e-4, atol=2e-3 * (T / 2048) ** 0.5)
+
+
+def test_gemm_tn_asymmetric_and_device_token_count(hip):
+    # exact integer data catches any fragment / swizzle mix-up: dY = one-hot rows, X = row index pattern
+    T, Mo, No = 256, 128, 256
+    dY = torch.zeros(T, Mo, device="cuda", dtype=torch.bfloat16)
+    dY[torch.arange(T), (torch.arange(T) * 7) % Mo] = 1.0
+    X = ((torch.arange(T * No, device="cuda").reshape(T, No) % 61) - 30).to(torch.bfloat16)
+    dW = torch.zeros(Mo, No, device="cuda")
+    hip.call("stonk_gemm_tn_bf16", hip.ptr(dY), Mo, hip.ptr(X), No, hip.ptr(dW), No, 0, Mo, No, T, 1.0, 2, 0,
+             hip.stream_ptr())
+    assert torch.equal(dW, dY.float().t() @ X.float())
+    # token count from device memory: rows in [k, roundup64(k)) are zero by contract, later K steps are skipped
+    k = 100
+    dY2, X2 = _rand((T, Mo), 1.0, 33), _rand((T, No), 1.0, 34)
+    dY2[k:128] = 0
+    X2[k:128] = 0
+    k_dev = torch.tensor([k], device="cuda", dtype=torch.int32)
+    dW2 = torch.zeros(Mo, No, device="cuda")
+    hip.call("stonk_gemm_tn_bf16", hip.ptr(dY2), Mo, hip.ptr(X2), No, hip.ptr(dW2), No, 0, Mo, No, T, 1.0, 1,
+             hip.ptr(k_dev), hip.stream_ptr())
+    torch.testing.assert_close(dW2, dY2[:k].float().t() @ X2[:k].float(), rtol=1e-4, atol=1e-3)

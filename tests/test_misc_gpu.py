@@ -95,7 +95,8 @@ def test_softmax_xent(hip, N):
     dl = torch.full((cap, npad), 5.0, device="cuda", dtype=torch.bfloat16)
     err = torch.zeros(1, device="cuda", dtype=torch.int32)
     hip.call("stonk_softmax_xent_fwd_bwd", hip.ptr(logits), npad, N, npad, hip.ptr(tg), hip.ptr(cnt), hip.ptr(loss),
-             hip.ptr(dl), npad, 1.0, hip.ptr(err), hip.stream_ptr())
+             hip.ptr(dl), npad, 1.0, cap, hip.ptr(err), hip.stream_ptr())
+    assert (dl[R:64] == 0).all() and (dl[64:] == 5.0).all()  # pad rows up to the 64-row K step are zeroed, no more
     x = logits[:R, :N].clone().requires_grad_(True)
     ref = F.cross_entropy(x, tg[:R].long())
     ref.backward()

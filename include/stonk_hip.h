@@ -133,6 +133,11 @@ int stonk_small_linear_bwd(const float* dy, const float* y, const void* x, int64
                            float* db, float* dx_f32, void* dx_bf16_accum, int64_t ld_dxb, int M, int N, int K, int act,
                            void* stream);
 
+/* Classification head plumbing (ref:src/stonkgs/models/stonkgs_finetuning.py:310-330): dropout on the pooled fp32
+ * vector (replayable from the seed), and *out = *num / *den for the mean of a device-side loss sum. */
+int stonk_dropout_f32(const float* x, float* y, int64_t n, float p, uint32_t seed, void* stream);
+int stonk_ratio_f32(const float* num, const float* den, float* out, void* stream);
+
 /* du = dg * gelu'(u), bf16 elementwise (backward of hf:modeling_bert.py:478, the head transform's activation). */
 int stonk_gelu_bwd_bf16(const void* dg, const void* u, void* du, int64_t n, void* stream);
 

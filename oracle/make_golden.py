@@ -38,7 +38,9 @@ def import_reference():
         sys.modules[name] = pkg
     const = types.ModuleType("stonkgs.constants")
     for k in ("EMBEDDINGS_PATH", "NLP_MODEL_TYPE", "PRETRAINING_DIR", "PRETRAINING_PATH", "RANDOM_WALKS_PATH",
-              "VOCAB_FILE"):
+              "VOCAB_FILE", "CELL_LINE_DIR", "CELL_TYPE_DIR", "CORRECT_DIR", "DEEPSPEED_CONFIG_PATH", "DISEASE_DIR",
+              "LOCATION_DIR", "MLFLOW_FINETUNING_TRACKING_URI", "ORGAN_DIR", "PRETRAINED_STONKGS_PATH",
+              "RELATION_TYPE_DIR", "SPECIES_DIR", "STONKGS_OUTPUT_DIR"):
         setattr(const, k, "/nonexistent/" + k)
     sys.modules["stonkgs.constants"] = const
     kgb = types.ModuleType("stonkgs.models.kg_baseline_model")
@@ -47,6 +49,14 @@ def import_reference():
     sm = importlib.import_module("stonkgs.models.stonkgs_model")
     pre = importlib.import_module("stonkgs.data.indra_for_pretraining")
     return sm, pre
+
+
+def import_reference_finetuning():
+    """ref:src/stonkgs/models/stonkgs_finetuning.py imports mlflow (experiment logging, absent here) at module level
+    for its cross-validation driver only; an empty module object lets the CLASS (forward :259-346) import unmodified."""
+    if "mlflow" not in sys.modules:
+        sys.modules["mlflow"] = types.ModuleType("mlflow")
+    return importlib.import_module("stonkgs.models.stonkgs_finetuning")
 
 
 def build_reference_model(sm, cfg: orc.OracleConfig, sd, tsv_rows):
@@ -191,6 +201,78 @@ def model_case(name, sm, pre, cfg: orc.OracleConfig, B, seed, full_logits):
     print(name, "loss", float(out.loss), "grad_norm", float(total_norm), "dead", len(dead))
 
 
+def classification_case(name, sm, ft, pre, cfg: orc.OracleConfig, B, seed, num_labels):
+    """G6: STonKGsForSequenceClassification (config 5) - the reference's fine-tuning forward, loss and gradients."""
+    from transformers import BertConfig, BertForPreTraining, BertModel
+
+    sd = orc.init_state_dict(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    tsv_rows = torch.randn(cfg.kg_vocab_size, cfg.hidden_size, generator=g, dtype=torch.float64) * 0.3
+    gw = torch.Generator().manual_seed(seed + 3)
+    sd["classifier.weight"] = (torch.randn(num_labels, cfg.hidden_size, generator=gw) * 0.02).to(torch.bfloat16).float()
+    sd["classifier.bias"] = (torch.randn(num_labels, generator=gw) * 0.02).to(torch.bfloat16).float()
+    hf_cfg = BertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+                        num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                        intermediate_size=cfg.intermediate_size, max_position_embeddings=cfg.max_position_embeddings,
+                        type_vocab_size=cfg.type_vocab_size, layer_norm_eps=cfg.layer_norm_eps,
+                        hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, attn_implementation="eager",
+                        num_labels=num_labels)
+    hf_cfg.update({"kg_vocab_size": cfg.kg_vocab_size})
+
+    class RefCls(ft.STonKGsForSequenceClassification):  # forward is the reference's; only the hub-fetching init is not
+        def __init__(self, c):
+            BertForPreTraining.__init__(self, c)
+            self.cls.predictions = sm.STonKGsELMPredictionHead(c)
+            self.lm_backbone = BertModel(c)
+            for p in self.lm_backbone.parameters():
+                p.requires_grad = False
+            self.lm_sep_id, self.lm_mask_id, self.lm_unk_id = 102, 103, 100
+            self.num_labels = c.num_labels
+            self.config = c
+            self.bert = BertModel(c)
+            self.dropout = torch.nn.Dropout(c.hidden_dropout_prob)
+            self.classifier = torch.nn.Linear(c.hidden_size, c.num_labels)
+
+    model = RefCls(hf_cfg)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(("position_ids" in k or "decoder" in k) for k in missing), (missing, unexpected)
+    model.eval()
+    K = cfg.kg_vocab_size
+    numeric_indices = [i for i in range(K + 3) if i not in (102, 103, 100)]
+    model.kg_backbone = {i: torch.tensor(tsv_rows[r].numpy()) for r, i in enumerate(numeric_indices)}
+    with torch.no_grad():
+        for sid in (102, 103, 100):
+            model.kg_backbone[sid] = model.lm_backbone(torch.tensor([[sid]]))[0][0][0]
+    batch = make_batch(cfg, B, seed + 2, pre)
+    rng = np.random.RandomState(seed + 4)
+    labels = torch.tensor(rng.randint(0, num_labels, B))
+    out = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
+                token_type_ids=batch["token_type_ids"], labels=labels, return_dict=True)
+    model.zero_grad()
+    out.loss.backward()
+    params = dict(model.named_parameters())
+    keys = ["classifier.weight", "classifier.bias", "bert.pooler.dense.weight",
+            "bert.encoder.layer.0.attention.self.query.weight", "bert.embeddings.position_embeddings.weight",
+            f"bert.encoder.layer.{cfg.num_hidden_layers - 1}.output.dense.bias"]
+    arrays = {k: batch[k].numpy() for k in ("input_ids", "attention_mask", "token_type_ids")}
+    arrays.update(labels=labels.numpy(), loss=out.loss.detach().numpy(), logits=out.logits.detach().numpy())
+    for k in keys:
+        arrays["grad::" + k] = params[k].grad.numpy()
+    total_norm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values() if p.grad is not None))
+    arrays["grad_norm"] = np.float32(total_norm.item())
+    meta = {"config": {k: getattr(cfg, k) for k in ("vocab_size", "kg_vocab_size", "hidden_size", "num_hidden_layers",
+                                                    "num_attention_heads", "intermediate_size",
+                                                    "max_position_embeddings", "type_vocab_size", "layer_norm_eps")},
+            "B": B, "weight_seed": seed, "table_seed": seed + 1, "batch_seed": seed + 2, "classifier_seed": seed + 3,
+            "num_labels": num_labels, "table_std": 0.3,
+            "weights_checksum": float(sum(v.double().abs().sum() for k, v in sd.items() if not k.startswith("classifier"))),
+            "table_checksum": float(tsv_rows.abs().sum()), "grad_keys": keys, "torch": torch.__version__}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(name, "loss", float(out.loss), "grad_norm", float(total_norm))
+
+
 def masking_case(pre):
     """G3/G4: integer-exact masking vectors and the entity index-space table."""
     res = {}
@@ -232,6 +314,12 @@ def main():
                                                        num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                                                        max_position_embeddings=256), B=3, seed=200, full_logits=False)
     masking_case(pre)
+    # G6: fine-tuning head (BASELINE config 5) on the HIP-supported small shape, 3 relation classes, ragged batch of 5
+    ft = import_reference_finetuning()
+    classification_case("g6_classification", sm, ft, pre,
+                        orc.OracleConfig(vocab_size=512, kg_vocab_size=300, hidden_size=128, num_hidden_layers=2,
+                                         num_attention_heads=2, intermediate_size=256, max_position_embeddings=256),
+                        B=5, seed=300, num_labels=3)
 
 
 if __name__ == "__main__":

@@ -189,6 +189,31 @@ def forward(sd: Dict[str, Tensor], cfg: OracleConfig, kg_table: Tensor, input_id
     return out
 
 
+def encode(sd, cfg: OracleConfig, kg_table: Tensor, input_ids, attention_mask=None, token_type_ids=None):
+    """Shared front of both models: steps 1-4 of `forward` (sequence_output, pooled_output)."""
+    half = cfg.half_length
+    token_embeddings = lm_backbone_forward(sd, cfg, input_ids[:, :half])
+    ent_ids = input_ids[:, half:]
+    if ent_ids.numel() and (int(ent_ids.min()) < 0 or int(ent_ids.max()) >= kg_table.shape[0]):
+        raise KeyError(int(ent_ids.max()))
+    inputs_embeds = torch.cat([token_embeddings, kg_table[ent_ids]], dim=1).to(torch.float32)
+    emb = bert_embeddings(sd, "bert.embeddings", cfg, inputs_embeds=inputs_embeds, token_type_ids=token_type_ids)
+    seq = bert_encoder(emb, sd, "bert.encoder", cfg, cfg.num_hidden_layers, attention_mask)
+    return seq, torch.tanh(_linear(seq[:, 0], sd, "bert.pooler.dense"))
+
+
+def forward_classification(sd, cfg: OracleConfig, kg_table: Tensor, input_ids, attention_mask=None, token_type_ids=None,
+                           labels=None) -> Dict[str, Tensor]:
+    """STonKGsForSequenceClassification.forward, single-label path (ref:src/stonkgs/models/stonkgs_finetuning.py:259-346):
+    same embedding front and encoder, pooled -> dropout (p = 0 here) -> classifier -> CrossEntropyLoss."""
+    seq, pooled = encode(sd, cfg, kg_table, input_ids, attention_mask, token_type_ids)
+    logits = _linear(pooled, sd, "classifier")
+    out = {"logits": logits, "pooler_output": pooled, "hidden_states": seq}
+    if labels is not None:
+        out["loss"] = F.cross_entropy(logits.view(-1, logits.shape[-1]), labels.view(-1))
+    return out
+
+
 # --------------------------------------------------------------------------------------------- parameters
 def trainable_names(sd: Dict[str, Tensor]) -> List[str]:
     """Parameters that receive a gradient in the reference (quirk Q4 removes the dead ones, lm_backbone is frozen)."""

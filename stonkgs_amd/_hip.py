@@ -59,6 +59,8 @@ _SIGNATURES = {
     "stonk_loss_finalize": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "stonk_small_linear_fwd": [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "stonk_small_linear_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
+    "stonk_dropout_f32": [_vp, _vp, _i64, _f32, _u32, _vp],
+    "stonk_ratio_f32": [_vp, _vp, _vp, _vp],
     "stonk_gelu_bwd_bf16": [_vp, _vp, _vp, _i64, _vp],
     "stonk_sumsq_f32": [_vp, _i64, _vp, _vp],
     "stonk_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _f32, _f32,

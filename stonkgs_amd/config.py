@@ -25,6 +25,8 @@ class STonKGsConfig:
     hidden_act: str = "gelu"
     initializer_range: float = 0.02
     model_type: str = "bert"
+    num_labels: int = 2                   # fine-tuning head only (ref:stonkgs_finetuning.py:247)
+    problem_type: str = None              # None -> inferred from num_labels / label dtype, as the reference does
 
     @property
     def half_length(self) -> int:  # ref:stonkgs_model.py:52

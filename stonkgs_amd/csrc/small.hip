@@ -152,3 +152,30 @@ extern "C" int stonk_gelu_bwd_bf16(const void* dg, const void* u, void* du, int6
                      (const bf16*)dg, (const bf16*)u, (bf16*)du, n8);
   return stonk_launch_status();
 }
+
+// Inverted dropout on a small fp32 tensor (the pooled vector in front of the classification head,
+// ref:src/stonkgs/models/stonkgs_finetuning.py:313); the same call with the same (seed) replays the mask on the gradient.
+namespace {
+__global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
+                                                          uint32_t thr24, float scale, uint32_t seed) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    y[i] = stonk_keep((uint32_t)i, seed, thr24) ? x[i] * scale : 0.f;
+}
+__global__ void ratio_kernel(const float* num, const float* den, float* out) { *out = *num / *den; }
+}  // namespace
+
+extern "C" int stonk_dropout_f32(const float* x, float* y, int64_t n, float p, uint32_t seed, void* stream) {
+  STONK_CHECK_ARG(x && y && n >= 0 && p >= 0.f && p < 1.f, STONK_EINVAL);
+  if (n == 0) return STONK_OK;
+  const long g = (n + 255) / 256;
+  hipLaunchKernelGGL(dropout_f32_kernel, dim3((unsigned)(g < 1024 ? g : 1024)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     (long)n, stonk_drop_thr24(p), 1.f / (1.f - p), seed);
+  return stonk_launch_status();
+}
+
+// *out = *num / *den on the device (mean of a cross-entropy sum without a host round trip)
+extern "C" int stonk_ratio_f32(const float* num, const float* den, float* out, void* stream) {
+  STONK_CHECK_ARG(num && den && out, STONK_EINVAL);
+  hipLaunchKernelGGL(ratio_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, num, den, out);
+  return stonk_launch_status();
+}

@@ -284,19 +284,19 @@ class Engine:
         return {102: out[0].clone(), 103: out[1].clone(), 100: out[2].clone()}
 
     # ------------------------------------------------------------------ forward
-    def forward(self, input_ids, attention_mask, token_type_ids, mlm_labels, ent_labels, nsp_labels, training: bool,
-                dense_logits: bool, need_backward: bool):
+    def encode(self, input_ids, attention_mask, token_type_ids, training: bool, save: dict):
+        """F1-F4: frozen backbone, KG gather + embeddings LayerNorm, encoder layers, pooler. Shared by the pre-training
+        and the sequence-classification models (ref:stonkgs_model.py:178-212, ref:stonkgs_finetuning.py:277-310)."""
         cfg = self.cfg
         H, S, half = cfg.hidden_size, cfg.max_position_embeddings, cfg.half_length
         B = input_ids.shape[0]
         T = B * S
         st = hip.stream_ptr()
         P = self.P
-        f, w = P.view, P.bf16_view
+        f = P.view
         self.seed_base += 1
         p_hid = cfg.hidden_dropout_prob if training else 0.0
         p_att = cfg.attention_probs_dropout_prob if training else 0.0
-        save: dict = {}
         # F1 frozen backbone (no attention mask: quirk Q5)
         text_hidden = self.backbone_fwd(input_ids, S, B, half, training)
         # F2 gather + concat + embeddings LayerNorm
@@ -314,10 +314,25 @@ class Engine:
         for i in range(cfg.num_hidden_layers):
             x = self.layer_fwd(P, f"bert.encoder.layer.{i}", x, B, S, attention_mask, p_hid, p_att, i, save)
         seq_out = x
-        # F4 pooler + NSP (fp32 master weights)
+        # F4 pooler (fp32 master weights)
         pooled = self.buf("h.pooled", (B, H), F32)
         hip.call("stonk_small_linear_fwd", seq_out.data_ptr(), S * H, f("bert.pooler.dense.weight").data_ptr(),
                  f("bert.pooler.dense.bias").data_ptr(), pooled.data_ptr(), B, H, H, hip.SMALL_TANH, st)
+        save.update(B=B, attention_mask=attention_mask, token_type_ids=token_type_ids, sum0=sum0, st0=st0,
+                    seq_out=seq_out, pooled=pooled, p_hid=p_hid, p_att=p_att)
+        return seq_out, pooled
+
+    def forward(self, input_ids, attention_mask, token_type_ids, mlm_labels, ent_labels, nsp_labels, training: bool,
+                dense_logits: bool, need_backward: bool):
+        cfg = self.cfg
+        H, S, half = cfg.hidden_size, cfg.max_position_embeddings, cfg.half_length
+        B = input_ids.shape[0]
+        T = B * S
+        st = hip.stream_ptr()
+        P = self.P
+        f, w = P.view, P.bf16_view
+        save: dict = {}
+        seq_out, pooled = self.encode(input_ids, attention_mask, token_type_ids, training, save)
         nsp = self.buf("h.nsp", (B, 2), F32)
         hip.call("stonk_small_linear_fwd", pooled.data_ptr(), H, f("cls.seq_relationship.weight").data_ptr(),
                  f("cls.seq_relationship.bias").data_ptr(), nsp.data_ptr(), B, 2, H, hip.SMALL_X_F32, st)
@@ -383,8 +398,7 @@ class Engine:
                 self.gemm(hs, w(wname), logits, cap, npad, H, flags=hip.EPI_OUT_F32)
                 out[f"{nm}_logits"] = logits[:, :N].view(B, half, N)
         if need_backward:
-            save.update(B=B, attention_mask=attention_mask, token_type_ids=token_type_ids, sum0=sum0, st0=st0,
-                        seq_out=seq_out, pooled=pooled, gt=gt, ut=ut, t=t, stt=stt, p_hid=p_hid, p_att=p_att)
+            save.update(gt=gt, ut=ut, t=t, stt=stt)
             self.saved = save
         return out
 
@@ -441,6 +455,16 @@ class Engine:
         hip.call("stonk_small_linear_bwd", dnsp.data_ptr(), 0, sv["pooled"].data_ptr(), H,
                  f("cls.seq_relationship.weight").data_ptr(), g_("cls.seq_relationship.weight").data_ptr(),
                  g_("cls.seq_relationship.bias").data_ptr(), dpooled.data_ptr(), 0, 0, B, 2, H, hip.SMALL_X_F32, st)
+        self.backward_encoder(dpooled, dseq, sv, notify)
+
+    def backward_encoder(self, dpooled, dseq, sv, notify) -> None:
+        """Pooler (tanh) backward into position 0 of d(sequence_output), encoder layers last to first, embeddings."""
+        cfg = self.cfg
+        H, S = cfg.hidden_size, cfg.max_position_embeddings
+        B = sv["B"]
+        T = B * S
+        st = hip.stream_ptr()
+        f, g_ = self.P.view, self.P.grad_view
         hip.call("stonk_small_linear_bwd", dpooled.data_ptr(), sv["pooled"].data_ptr(), sv["seq_out"].data_ptr(), S * H,
                  f("bert.pooler.dense.weight").data_ptr(), g_("bert.pooler.dense.weight").data_ptr(),
                  g_("bert.pooler.dense.bias").data_ptr(), 0, dseq.data_ptr(), S * H, B, H, H, hip.SMALL_TANH, st)
@@ -462,3 +486,62 @@ class Engine:
                  g_("bert.embeddings.position_embeddings.weight").data_ptr(),
                  g_("bert.embeddings.token_type_embeddings.weight").data_ptr(), B, S, H, cfg.type_vocab_size, st)
         notify("bert.embeddings")
+
+    # ------------------------------------------------------------------ sequence classification head (config 5)
+    def forward_cls(self, input_ids, attention_mask, token_type_ids, labels, num_labels: int, training: bool,
+                    need_backward: bool):
+        """pooled -> dropout -> Linear(H, num_labels) -> CrossEntropyLoss (ref:stonkgs_finetuning.py:310-330)."""
+        cfg = self.cfg
+        H = cfg.hidden_size
+        B = input_ids.shape[0]
+        st = hip.stream_ptr()
+        f = self.P.view
+        save: dict = {}
+        seq_out, pooled = self.encode(input_ids, attention_mask, token_type_ids, training, save)
+        p = cfg.hidden_dropout_prob if training else 0.0
+        dropped = pooled
+        if p > 0:
+            dropped = self.buf("c.dropped", (B, H), F32)
+            hip.call("stonk_dropout_f32", pooled.data_ptr(), dropped.data_ptr(), B * H, p, self.seed(300, 0), st)
+        logits = self.buf("c.logits", (B, num_labels), F32)
+        hip.call("stonk_small_linear_fwd", dropped.data_ptr(), H, f("classifier.weight").data_ptr(),
+                 f("classifier.bias").data_ptr(), logits.data_ptr(), B, num_labels, H, hip.SMALL_X_F32, st)
+        out = dict(logits=logits, hidden_states=seq_out.view(B, cfg.max_position_embeddings, H), pooler_output=pooled)
+        if labels is not None:
+            acc = self.buf("c.acc", (2,), F32)
+            acc.zero_()
+            dl = self.buf("c.dl", (B, num_labels), F32) if need_backward else None
+            hip.call("stonk_nsp_xent_fwd_bwd", logits.data_ptr(), labels.data_ptr(), B, num_labels, acc.data_ptr(),
+                     hip.ptr(dl), 1.0, self.err.data_ptr(), st)
+            loss = self.buf("c.loss", (1,), F32)
+            hip.call("stonk_ratio_f32", acc[0:1].data_ptr(), acc[1:2].data_ptr(), loss.data_ptr(), st)
+            out["loss"] = loss[0]
+            if need_backward:
+                save.update(dl=dl, dropped=dropped, p_cls=p, num_labels=num_labels)
+                self.saved = save
+        return out
+
+    def backward_cls(self, gscale: float = 1.0, on_segment_done: Optional[Callable[[str], None]] = None) -> None:
+        sv = self.saved
+        if sv is None:
+            raise RuntimeError("backward_cls() without a training forward (labels are required)")
+        self.saved = None
+        cfg = self.cfg
+        H, S = cfg.hidden_size, cfg.max_position_embeddings
+        B, C = sv["B"], sv["num_labels"]
+        st = hip.stream_ptr()
+        f, g_ = self.P.view, self.P.grad_view
+        notify = on_segment_done or (lambda name: None)
+        dl = sv["dl"]
+        if gscale != 1.0:
+            hip.call("stonk_scale_f32", dl.data_ptr(), dl.numel(), gscale, st)
+        dpooled = self.buf("b.dpooled", (B, H), F32)
+        hip.call("stonk_small_linear_bwd", dl.data_ptr(), 0, sv["dropped"].data_ptr(), H, f("classifier.weight").data_ptr(),
+                 g_("classifier.weight").data_ptr(), g_("classifier.bias").data_ptr(), dpooled.data_ptr(), 0, 0, B, C, H,
+                 hip.SMALL_X_F32, st)
+        if sv["p_cls"] > 0:  # same (seed, index) mask as the forward
+            hip.call("stonk_dropout_f32", dpooled.data_ptr(), dpooled.data_ptr(), B * H, sv["p_cls"], self.seed(300, 0), st)
+        notify("classifier.bias")
+        dseq = self.buf("b.dseq", (B * S, H))
+        dseq.zero_()  # only position 0 of every sequence receives a gradient (from the pooler)
+        self.backward_encoder(dpooled, dseq, sv, notify)

@@ -93,9 +93,9 @@ def _layer_specs(prefix: str, H: int, I: int):
     ]
 
 
-def trainable_specs(cfg: STonKGsConfig):
-    H, I, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
-    specs = [
+def pretraining_head_specs(cfg: STonKGsConfig):
+    H = cfg.hidden_size
+    return [
         ("cls.predictions.entity_decoder.weight", (cfg.kg_vocab_size, H), pad128(cfg.kg_vocab_size)),
         ("cls.predictions.text_decoder.weight", (cfg.vocab_size, H), pad128(cfg.vocab_size)),
         ("cls.predictions.transform.dense.weight", (H, H), None),
@@ -104,6 +104,12 @@ def trainable_specs(cfg: STonKGsConfig):
         ("cls.predictions.transform.LayerNorm.bias", (H,), None),
         ("cls.seq_relationship.weight", (2, H), None),
         ("cls.seq_relationship.bias", (2,), None),
+    ]
+
+
+def trainable_specs(cfg: STonKGsConfig, with_pretraining_heads: bool = True):
+    H, I, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    specs = (pretraining_head_specs(cfg) if with_pretraining_heads else []) + [
         ("bert.pooler.dense.weight", (H, H), None),
         ("bert.pooler.dense.bias", (H,), None),
     ]

@@ -25,7 +25,8 @@ from torch import nn
 from . import _hip as hip
 from .config import STonKGsConfig
 from .engine import Engine
-from .params import FlatStore, _Node, _linear, _param, backbone_specs, build_bert_tree, trainable_specs
+from .params import (FlatStore, _Node, _linear, _param, backbone_specs, build_bert_tree, pretraining_head_specs,
+                     trainable_specs)
 
 SEP_ID, MASK_ID, UNK_ID = 102, 103, 100  # BioBERT vocabulary (ref:stonkgs_model.py:116-118)
 
@@ -88,15 +89,15 @@ class KGBackbone:
 class STonKGsELMPredictionHead(_Node):
     """Naming mirror of ref:stonkgs_model.py:37-73 (transform, split text/entity decoders, dead biases)."""
 
-    def __init__(self, config: STonKGsConfig, store: FlatStore, device):
+    def __init__(self, config: STonKGsConfig, store: FlatStore, device, trainable: bool = True):
         super().__init__()
         H = config.hidden_size
         tr = _Node()
-        tr.dense = _linear(store, "cls.predictions.transform.dense", True)
-        tr.LayerNorm = _linear(store, "cls.predictions.transform.LayerNorm", True)
+        tr.dense = _linear(store, "cls.predictions.transform.dense", trainable)
+        tr.LayerNorm = _linear(store, "cls.predictions.transform.LayerNorm", trainable)
         self.transform = tr
-        self.text_decoder = _linear(store, "cls.predictions.text_decoder", True, bias=False)
-        self.entity_decoder = _linear(store, "cls.predictions.entity_decoder", True, bias=False)
+        self.text_decoder = _linear(store, "cls.predictions.text_decoder", trainable, bias=False)
+        self.entity_decoder = _linear(store, "cls.predictions.entity_decoder", trainable, bias=False)
         self.half_length = config.max_position_embeddings // 2
         # dead parameters (quirk Q4): declared, serialised, never used by forward, never updated
         self.bias = nn.Parameter(torch.zeros(config.vocab_size, device=device), requires_grad=False)
@@ -126,6 +127,8 @@ class _StepFunction(torch.autograd.Function):
 
 
 class STonKGsForPreTraining(nn.Module):
+    _TRAIN_PRETRAINING_HEADS = True
+
     def __init__(self, config=None, nlp_model_type: Optional[str] = None, kg_embedding_dict_path: Optional[str] = None,
                  *, kg_embeddings: Optional[torch.Tensor] = None, kg_names=None, device=None, seed: int = 0,
                  backbone_layers: Optional[int] = None):
@@ -163,15 +166,20 @@ class STonKGsForPreTraining(nn.Module):
         cfg.validate_for_hip()
         dev = self._device
         n_bb = cfg.num_hidden_layers if backbone_layers is None else backbone_layers
-        self._store = FlatStore(trainable_specs(cfg), dev, trainable=True)
+        self._store = FlatStore(self._head_specs(cfg) + trainable_specs(cfg, self._TRAIN_PRETRAINING_HEADS), dev,
+                                trainable=True)
+        # the fine-tuning subclass inherits the MLM/ELM/NSP heads (they stay in its checkpoints) but never uses them:
+        # there they live in a frozen side store - no gradient buffer, no optimizer state, no all-reduce bytes
+        heads = self._store if self._TRAIN_PRETRAINING_HEADS else FlatStore(pretraining_head_specs(cfg), dev, False)
+        self._heads_store = heads
         self._bb_store = FlatStore(backbone_specs(cfg, n_bb), dev, trainable=False)
         # ---- module tree (names only)
         dead_we = nn.Parameter(torch.zeros(cfg.vocab_size, cfg.hidden_size, device=dev), requires_grad=False)
         self.bert = build_bert_tree(self._store, "bert", cfg, cfg.num_hidden_layers, True, dead_we)
         cls = _Node()
-        cls.predictions = STonKGsELMPredictionHead(cfg, self._store, dev)
+        cls.predictions = STonKGsELMPredictionHead(cfg, heads, dev, self._TRAIN_PRETRAINING_HEADS)
         cls.predictions.decoder.weight = dead_we  # tied: cls.predictions.decoder.weight <-> word_embeddings (both dead)
-        cls.seq_relationship = _linear(self._store, "cls.seq_relationship", True)
+        cls.seq_relationship = _linear(heads, "cls.seq_relationship", self._TRAIN_PRETRAINING_HEADS)
         self.cls = cls
         self.lm_backbone = build_bert_tree(self._bb_store, "lm_backbone", cfg, n_bb, False, None)
         self.lm_sep_id, self.lm_mask_id, self.lm_unk_id = SEP_ID, MASK_ID, UNK_ID
@@ -200,12 +208,17 @@ class STonKGsForPreTraining(nn.Module):
         self.refresh()
 
     # -------------------------------------------------------------- construction helpers
+    @staticmethod
+    def _head_specs(cfg):
+        """Extra trainable tensors a subclass puts in FRONT of the flat buffer (their gradients are final first)."""
+        return []
+
     def _init_weights(self, seed: int) -> None:
         """BERT init (hf _init_weights: N(0, initializer_range) matrices/embeddings, zero bias, unit LayerNorm)."""
         g = torch.Generator(device="cpu").manual_seed(seed)
         std = self.config.initializer_range
         with torch.no_grad():
-            for store in (self._store, self._bb_store):
+            for store in {id(x): x for x in (self._store, self._bb_store, self._heads_store)}.values():
                 for name, (off, shape, _) in store.index.items():
                     v = store.view(name)
                     if "LayerNorm.weight" in name:
@@ -347,6 +360,112 @@ class STonKGsForPreTraining(nn.Module):
                                   self.training, False, True)
         loss = out["loss"].clone()
         self.engine.backward(gscale, on_segment_done)
+        return loss
+
+
+@dataclass
+class SequenceClassifierOutput:
+    """hf:modeling_outputs.SequenceClassifierOutput as returned by ref:stonkgs_finetuning.py:340-345."""
+
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    hidden_states: Optional[tuple] = None
+    attentions: Optional[tuple] = None
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return getattr(self, k)
+        return tuple(v for v in (self.loss, self.logits, self.hidden_states, self.attentions) if v is not None)[k]
+
+
+class _ClsStepFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, loss):
+        ctx.model = model
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        model = ctx.model
+        model.engine.backward_cls(float(dloss), model._segment_hook)
+        model._reattach_grads()
+        return None, None, None
+
+
+class STonKGsForSequenceClassification(STonKGsForPreTraining):
+    """Fine-tuning model of BASELINE config 5 (relation-type etc. classification): mirror of
+    ref:src/stonkgs/models/stonkgs_finetuning.py:237-346. Same frozen LM backbone + KG table front, same encoder,
+    pooled [CLS] -> dropout -> Linear(hidden, num_labels) -> CrossEntropyLoss. Like the reference it inherits from the
+    pre-training class (its MLM/ELM heads stay in the state dict, unused). Only `single_label_classification` is
+    implemented on the HIP path; the regression / multi-label branches of the reference raise NotImplementedError."""
+
+    _TRAIN_PRETRAINING_HEADS = False
+
+    def __init__(self, config, **kwargs):
+        cfg = STonKGsConfig.from_any(config) if config is not None else None
+        if "num_labels" in kwargs:  # from_pretrained(model_path, num_labels=n) as the reference calls it (:404-407)
+            n = kwargs.pop("num_labels")
+            if cfg is not None:
+                cfg.num_labels = n
+        super().__init__(cfg, **kwargs)
+        self.num_labels = self.config.num_labels
+        self.dropout = nn.Dropout(self.config.hidden_dropout_prob)  # naming only; the engine applies it
+        self.classifier = _linear(self._store, "classifier", True)
+        self._grad_views = {n: p.grad for n, p in self.named_parameters() if p.requires_grad}
+
+    @staticmethod
+    def _head_specs(cfg):
+        return [("classifier.weight", (cfg.num_labels, cfg.hidden_size), None), ("classifier.bias", (cfg.num_labels,), None)]
+
+    def _prep(self, t):
+        if t is None:
+            return None
+        t = torch.as_tensor(t)
+        if t.device != self._device or t.dtype != torch.long or not t.is_contiguous():
+            t = t.to(device=self._device, dtype=torch.long).contiguous()
+        return t
+
+    def _check_problem_type(self, labels):
+        if labels is None:
+            return
+        pt = self.config.problem_type
+        if pt is None:  # ref:stonkgs_finetuning.py:318-326
+            lt = torch.as_tensor(labels)
+            if self.num_labels == 1:
+                pt = "regression"
+            elif self.num_labels > 1 and lt.dtype in (torch.long, torch.int):
+                pt = "single_label_classification"
+            else:
+                pt = "multi_label_classification"
+            self.config.problem_type = pt
+        if pt != "single_label_classification":
+            raise NotImplementedError(f"problem_type {pt!r}: only single_label_classification runs on the HIP path")
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
+                inputs_embeds=None, labels=None, output_attentions=None, output_hidden_states=None, return_dict=None):
+        if input_ids is None:
+            raise ValueError("input_ids is required")
+        self._check_problem_type(labels)
+        ids, am, tt, lab = self._prep(input_ids), self._prep(attention_mask), self._prep(token_type_ids), self._prep(labels)
+        training = self.training
+        need_bwd = lab is not None and torch.is_grad_enabled() and training
+        out = self.engine.forward_cls(ids, am, tt, lab, self.num_labels, training, need_bwd)
+        loss = None
+        if lab is not None:
+            loss = _ClsStepFunction.apply(self._anchor, self, out["loss"]) if need_bwd else out["loss"].clone()
+        logits = out["logits"].clone()
+        if not return_dict:
+            return ((loss,) + (logits,)) if loss is not None else (logits,)
+        return SequenceClassifierOutput(loss=loss, logits=logits, hidden_states=None, attentions=None)
+
+    def forward_backward(self, inputs, gscale: float = 1.0, on_segment_done=None):
+        labels = inputs.get("labels")
+        self._check_problem_type(labels)
+        out = self.engine.forward_cls(self._prep(inputs["input_ids"]), self._prep(inputs.get("attention_mask")),
+                                      self._prep(inputs.get("token_type_ids")), self._prep(labels), self.num_labels,
+                                      self.training, True)
+        loss = out["loss"].clone()
+        self.engine.backward_cls(gscale, on_segment_done)
         return loss
 
 

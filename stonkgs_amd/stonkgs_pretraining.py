@@ -155,9 +155,12 @@ class GradSynchronizer:
 def segment_ends_for(model) -> Dict[str, int]:
     """Map the engine's backward notifications to end offsets in the flat gradient buffer."""
     store, cfg = model._store, model.config
-    seg = {"cls.predictions.entity_decoder.weight": store.span("cls.predictions.entity_decoder.weight")[1],
-           "cls.predictions.text_decoder.weight": store.span("cls.predictions.text_decoder.weight")[1],
-           "bert.pooler.dense.bias": store.span("bert.pooler.dense.bias")[1]}
+    seg = {}
+    if "classifier.bias" in store.index:
+        seg["classifier.bias"] = store.span("classifier.bias")[1]
+    for name in ("cls.predictions.entity_decoder.weight", "cls.predictions.text_decoder.weight", "bert.pooler.dense.bias"):
+        if name in store.index:
+            seg[name] = store.span(name)[1]
     for i in range(cfg.num_hidden_layers):
         seg[f"bert.encoder.layer.{i}"] = store.span(f"bert.encoder.layer.{i}.output.LayerNorm.bias")[1]
     seg["bert.embeddings"] = store.numel

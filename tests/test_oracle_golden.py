@@ -97,3 +97,36 @@ def test_out_of_table_entity_raises_keyerror(case):
         bad["input_ids"][0, -1] = cfg.kg_vocab_size + 3
         with pytest.raises(KeyError):
             orc.forward(sd, cfg, table, **bad)
+
+
+def test_classification_head_matches_reference():
+    """G6: the reference's STonKGsForSequenceClassification.forward (single-label CE), ragged batch of 5, 3 classes."""
+    import json
+    import os
+
+    with open(os.path.join(GOLDEN, "g6_classification.json")) as f:
+        meta = json.load(f)
+    gold = dict(np.load(os.path.join(GOLDEN, "g6_classification.npz")))
+    cfg = orc.OracleConfig(**meta["config"])
+    sd = orc.init_state_dict(cfg, seed=meta["weight_seed"])
+    assert abs(float(sum(v.double().abs().sum() for v in sd.values())) - meta["weights_checksum"]) < 1e-6
+    gw = torch.Generator().manual_seed(meta["classifier_seed"])
+    nl, H = meta["num_labels"], cfg.hidden_size
+    sd["classifier.weight"] = (torch.randn(nl, H, generator=gw) * 0.02).to(torch.bfloat16).float()
+    sd["classifier.bias"] = (torch.randn(nl, generator=gw) * 0.02).to(torch.bfloat16).float()
+    g = torch.Generator().manual_seed(meta["table_seed"])
+    rows = torch.randn(cfg.kg_vocab_size, H, generator=g, dtype=torch.float64) * meta["table_std"]
+    with torch.no_grad():
+        table = orc.build_kg_table(rows, orc.special_vectors(sd, cfg))
+    names = [k for k in sd if k.startswith("bert.") and "word_embeddings" not in k] + ["classifier.weight", "classifier.bias"]
+    params = {k: sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(sd)
+    work.update(params)
+    out = orc.forward_classification(work, cfg, table, torch.from_numpy(gold["input_ids"]),
+                                     torch.from_numpy(gold["attention_mask"]), torch.from_numpy(gold["token_type_ids"]),
+                                     torch.from_numpy(gold["labels"]))
+    assert abs(float(out["loss"]) - float(gold["loss"])) < 1e-5
+    np.testing.assert_allclose(out["logits"].detach().numpy(), gold["logits"], rtol=1e-4, atol=1e-5)
+    out["loss"].backward()
+    for k in meta["grad_keys"]:
+        np.testing.assert_allclose(params[k].grad.numpy(), gold["grad::" + k], rtol=2e-4, atol=2e-6, err_msg=k)

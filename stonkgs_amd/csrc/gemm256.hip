@@ -188,53 +188,81 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     char* ep = smem + LDS_STAGES + wave * 4096;
     const int flags = p.flags;
     const int wm = lane & 15, wq = lane >> 4;   // write side: row, 4-column group inside a 16x16 fragment tile
+    const int rrow = lane >> 3, c8 = lane & 7;  // read side: 8 lanes x 8 columns = one 128-byte (bf16) line per row
+    const int n0 = w.n0 + wc * 64;
+    const int n = n0 + c8 * 8;
+    const bool n_ok = n < N;
+    const int mbase = w.m0 + wr * 128;
+    // this lane's 8 output columns are the same for every row of the tile: bias once per tile
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+    if ((flags & STONK_EPI_BIAS) && n_ok) {
+      b0 = *(const f32x4*)(p.bias + n);
+      b1 = *(const f32x4*)(p.bias + n + 4);
+    }
+    SideOps side[2][2];   // [round parity][half]: residual / saved pre-activation, fetched one round ahead
+    if (OUT_MODE != 2) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int h = 0; h < 2; ++h) {
+        const int mm = mbase + h * 8 + rrow;
+        side_prefetch(side[0][h], p, flags, mm, n, mm < M && n_ok);
+      }
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+    for (int rd = 0; rd < 8; ++rd) {
+      const int a = rd >> 2, i = rd & 3;
+      const int m = mbase + a * 64 + i * 16;
+      if (OUT_MODE != 2 && rd + 1 < 8) {
+        const int mnext = mbase + ((rd + 1) >> 2) * 64 + ((rd + 1) & 3) * 16;
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int h = 0; h < 2; ++h) {
+          const int mm = mnext + h * 8 + rrow;
+          side_prefetch(side[(rd + 1) & 1][h], p, flags, mm, n, mm < M && n_ok);
+        }
+      }
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int ch = b * 8 + j * 4 + wq;  // 16-byte chunk of the 256-byte row
-            *(f32x4*)(ep + wm * 256 + ((ch ^ wm) << 4)) = acc[a][b][i][j] * p.alpha;
-          }
-        __builtin_amdgcn_wave_barrier();
-        const int m = w.m0 + wr * 128 + a * 64 + i * 16;
-        const int n0 = w.n0 + wc * 64;
-        if (OUT_MODE == 2) {
-          // fp32 accumulate: one atomic wave-instruction = 64 consecutive floats of one row (256 contiguous bytes)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float x = *(const float*)(ep + r * 256 + (((lane >> 2) ^ r) << 4) + (lane & 3) * 4);
-            if (m + r < M && n0 + lane < N) atomicAdd((float*)p.C + (long)(m + r) * p.ldc + n0 + lane, x);
-          }
-        } else {
-          // read side: 8 lanes x 8 columns = one full 128-byte (bf16) output line per row, 8 rows per instruction
+        for (int j = 0; j < 2; ++j) {
+          const int ch = b * 8 + j * 4 + wq;  // 16-byte chunk of the 256-byte row
+          *(f32x4*)(ep + wm * 256 + ((ch ^ wm) << 4)) = acc[a][b][i][j] * p.alpha;
+        }
+      __builtin_amdgcn_wave_barrier();
+      if (OUT_MODE == 2) {
+        // fp32 accumulate: one atomic wave-instruction = 64 consecutive floats of one row (256 contiguous bytes)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int row = h * 8 + (lane >> 3), c8 = lane & 7;
-            const f32x4 q0 = *(const f32x4*)(ep + row * 256 + (((2 * c8) ^ row) << 4));
-            const f32x4 q1 = *(const f32x4*)(ep + row * 256 + (((2 * c8 + 1) ^ row) << 4));
-            const int mm = m + row, n = n0 + c8 * 8;
-            if (mm < M && n < N) {
-              float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-              epilogue8(v, p, flags, mm, n);
-              if (OUT_MODE == 0) {
-                bf16x8 o;
+        for (int r = 0; r < 16; ++r) {
+          const float x = *(const float*)(ep + r * 256 + (((lane >> 2) ^ r) << 4) + (lane & 3) * 4);
+          if (m + r < M && n0 + lane < N) atomicAdd((float*)p.C + (long)(m + r) * p.ldc + n0 + lane, x);
+        }
+      } else {
+        f32x4 q[2][2];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                *(bf16x8*)((bf16*)p.C + (long)mm * p.ldc + n) = o;
-              } else {
-                float* dst = (float*)p.C + (long)mm * p.ldc + n;
-                *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-                *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-              }
+        for (int h = 0; h < 2; ++h) {
+          const int row = h * 8 + rrow;
+          q[h][0] = *(const f32x4*)(ep + row * 256 + (((2 * c8) ^ row) << 4));
+          q[h][1] = *(const f32x4*)(ep + row * 256 + (((2 * c8 + 1) ^ row) << 4));
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int mm = m + h * 8 + rrow;
+          if (mm < M && n_ok) {
+            float v[8] = {q[h][0][0], q[h][0][1], q[h][0][2], q[h][0][3], q[h][1][0], q[h][1][1], q[h][1][2], q[h][1][3]};
+            epilogue8_pre(v, p, flags, mm, n, b0, b1, side[rd & 1][h]);
+            if (OUT_MODE == 0) {
+              bf16x8 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+              *(bf16x8*)((bf16*)p.C + (long)mm * p.ldc + n) = o;
+            } else {
+              float* dst = (float*)p.C + (long)mm * p.ldc + n;
+              *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+              *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
             }
           }
         }
-        __builtin_amdgcn_wave_barrier();
       }
+      __builtin_amdgcn_wave_barrier();
+    }
   };
 
   // ------------------------------------------------------------------ stream of K tiles

@@ -252,7 +252,10 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   // large launches go to the persistent 256x256 kernel (gemm256.hip); small ones keep the 128x128 tiles
   // measured on MI355X (tools/bench_kernels.py): the 256x256 kernel wins for wide outputs (N >= 2304, where its
   // halved operand traffic per flop outweighs one-workgroup-per-CU epilogues); N = 768 quantises badly (3 column tiles)
-  const bool big = M >= 1024 && N >= 1536 && out_mode != STONK_EPI_OUT_F32_ATOMIC;
+  // ... and epilogues that READ a second [M,N] operand (residual, saved pre-activation) still favour two co-resident
+  // workgroups per CU hiding each other's load latency (tools/bench_epilogue.py)
+  const bool big = M >= 1024 && N >= 1536 && out_mode != STONK_EPI_OUT_F32_ATOMIC &&
+                   !(flags & (STONK_EPI_GELU_BWD | STONK_EPI_RESID));
   // its epilogue moves 16-byte row segments: strides of every side operand must keep them aligned
   const bool v2_ok = ldc % 8 == 0 && (!(flags & STONK_EPI_RESID) || (ldr % 8 == 0 && (uintptr_t)resid % 16 == 0)) &&
                      (!(flags & (STONK_EPI_SAVE_PREACT | STONK_EPI_GELU_BWD)) ||

@@ -101,4 +101,49 @@ __device__ __forceinline__ void epilogue8(float (&v)[8], const GemmArgs& p, int 
   }
 }
 
+// Side operands of one epilogue8 call, fetched AHEAD of their use (one round earlier) so that the global-load latency
+// of the residual / saved pre-activation is not paid once per 16-row round.
+struct SideOps {
+  bf16x8 aux, res;
+};
+__device__ __forceinline__ void side_prefetch(SideOps& s, const GemmArgs& p, int flags, int m, int n, bool ok) {
+  if (!ok) return;
+  if (flags & STONK_EPI_GELU_BWD) s.aux = *(const bf16x8*)(p.aux + (long)m * p.ldaux + n);
+  if (flags & STONK_EPI_RESID) s.res = *(const bf16x8*)(p.resid + (long)m * p.ldr + n);
+}
+// epilogue8 with preloaded bias (8 columns of this lane, fixed for the whole tile) and side operands
+__device__ __forceinline__ void epilogue8_pre(float (&v)[8], const GemmArgs& p, int flags, int m, int n, const f32x4& b0,
+                                              const f32x4& b1, const SideOps& s) {
+  if (flags & STONK_EPI_BIAS) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] += b0[r];
+      v[4 + r] += b1[r];
+    }
+  }
+  if (flags & STONK_EPI_SAVE_PREACT) {
+    bf16x8 u;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) u[r] = (bf16)v[r];
+    *(bf16x8*)(p.aux + (long)m * p.ldaux + n) = u;
+  }
+  if (flags & STONK_EPI_GELU) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = gelu_erf(v[r]);
+  }
+  if (flags & STONK_EPI_GELU_BWD) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad((float)s.aux[r]);
+  }
+  if (flags & STONK_EPI_DROPOUT) {
+    const uint32_t e = (uint32_t)((long)m * p.N + n);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = stonk_keep(e + r, p.seed, p.drop_thr24) ? v[r] * p.drop_scale : 0.f;
+  }
+  if (flags & STONK_EPI_RESID) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] += (float)s.res[r];
+  }
+}
+
 }  // namespace stonk_gemm

@@ -46,7 +46,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // FFN GEMMs are VALU-bound on it otherwise. Also returns exp(-x^2) for the derivative.
 __device__ __forceinline__ float erf_as(float x, float& e_mx2) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));  // v_rcp_f32 (1 ulp), not the IEEE division sequence
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);

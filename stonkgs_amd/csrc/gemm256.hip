@@ -46,7 +46,10 @@ struct Work {
   int nk;           // K tiles in this work item
 };
 
-template <int OUT_MODE>
+// EPI >= 0: the epilogue flags are a compile-time constant (no dead side-operand loads for the compiler to guard with
+// vmcnt(0) - such a wait inside the epilogue rounds also waits for the previous round's STORES and costs ~2 us per
+// round); EPI < 0: flags read from the arguments at run time (rare combinations).
+template <int OUT_MODE, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -140,7 +143,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   const int b_row0 = wc * 32 * 128;   // this wave-col's 32 rows of a B half
 
   f32x4 acc[2][2][4][2];
-  auto zero_acc = [&]() {
+  // The bias enters through the accumulators' initial value (C = bias + A.B, alpha == 1 enforced by the launcher): a
+  // lane's 4 consecutive columns of fragment tile (b, j) are the same for every row block, so 4 quads per lane per
+  // tile. They are loaded for the NEXT tile at the top of the tile boundary, BEFORE its DMA and stores are issued, so
+  // the wait the compiler puts in front of init_acc is a counted one that the boundary's own wait already satisfied.
+  f32x4 bq[2][2];
+  auto load_bias_quads = [&](const Work& w) {
+    const int flags = EPI >= 0 ? EPI : p.flags;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = w.n0 + wc * 64 + b * 32 + j * 16 + (lane >> 4) * 4;
+        bq[b][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if ((flags & STONK_EPI_BIAS) && n < N) bq[b][j] = *(const f32x4*)(p.bias + n);
+      }
+  };
+  auto init_acc = [&]() {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -148,9 +167,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int j = 0; j < 2; ++j) acc[a][b][i][j] = bq[b][j];
   };
-  bf16x8 fa[2][4], fb[2][2];  // [k-step][tile]
+  bf16x8 fa[2][4], fb0[2][2], fb1[2][2];  // [k-step][tile]
   auto read_a = [&](int buf, int slot) {
     const char* s = smem + buf * STAGE_BYTES + slot * HALF_BYTES + a_row0 + frag_off;
 #pragma unroll
@@ -158,14 +177,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[ks][i] = *(const bf16x8*)(s + i * 2048 + (((ks * 4 + kc) ^ swz) << 4));
   };
-  auto read_b = [&](int buf, int slot) {
+  auto read_b = [&](int buf, int slot, bf16x8 (&fb)[2][2]) {
     const char* s = smem + buf * STAGE_BYTES + slot * HALF_BYTES + b_row0 + frag_off;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int j = 0; j < 2; ++j) fb[ks][j] = *(const bf16x8*)(s + j * 2048 + (((ks * 4 + kc) ^ swz) << 4));
   };
-  auto mma = [&](f32x4 (&c)[4][2]) {
+  auto mma = [&](f32x4 (&c)[4][2], const bf16x8 (&fb)[2][2]) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -186,19 +205,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // next tile keeps running underneath.
   auto store_tile = [&](const Work& w) {
     char* ep = smem + LDS_STAGES + wave * 4096;
-    const int flags = p.flags;
+    const int flags = (EPI >= 0 ? EPI : p.flags) & ~STONK_EPI_BIAS;
     const int wm = lane & 15, wq = lane >> 4;   // write side: row, 4-column group inside a 16x16 fragment tile
     const int rrow = lane >> 3, c8 = lane & 7;  // read side: 8 lanes x 8 columns = one 128-byte (bf16) line per row
     const int n0 = w.n0 + wc * 64;
     const int n = n0 + c8 * 8;
     const bool n_ok = n < N;
     const int mbase = w.m0 + wr * 128;
-    // this lane's 8 output columns are the same for every row of the tile: bias once per tile
-    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-    if ((flags & STONK_EPI_BIAS) && n_ok) {
-      b0 = *(const f32x4*)(p.bias + n);
-      b1 = *(const f32x4*)(p.bias + n + 4);
-    }
+    // (the bias is already inside the accumulators: they were INITIALISED with it, see init_acc)
+    const f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
     SideOps side[2][2];   // [round parity][half]: residual / saved pre-activation, fetched one round ahead
     if (OUT_MODE != 2) {
 #pragma unroll
@@ -292,6 +307,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     }
   };
 
+  load_bias_quads(cw);
+  init_acc();
   // prologue: the whole first K tile
   issue(SLOT_A0, 0);
   issue(SLOT_B0, 0);
@@ -301,79 +318,118 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   wait_vm4();   // A-first, B-first landed (this wave's part)
   barrier();
   if (wr == 1) barrier();   // second wave-row runs one barrier behind
-  zero_acc();
 
   int buf = 0;    // stage holding the compute K tile
-  // `fresh`: first K tile after a tile boundary. There every DMA issued so far has already been waited for (before
-  // the epilogue stores were issued), so phases 0-2 need no wait - and must not have one: vmcnt counts in order, a
-  // wait there would sit behind the 16 epilogue stores of this wave. Their drain hides under these three phases.
-  bool fresh = false;
+  // ---- tile boundary protocol. vmcnt retires in issue order, so a DMA wait placed AFTER the epilogue's stores in
+  // program order would also wait for those stores (128 KiB per workgroup draining at the store path's pace). The
+  // boundary therefore (E1) issues the WHOLE next-but-one K tile into the stage that has just been consumed, (E2)
+  // waits for the next K tile to land, and only then (E3) issues the stores. The two K tiles after a boundary use
+  // waits whose counts skip over the S stores (`mode` 1: no issue, one wait; `mode` 2: normal issue, waits +S); the
+  // first wait that has to see the stores retired comes 7 phases after they were issued.
+  const int S = (OUT_MODE == 0) ? (((EPI >= 0 ? EPI : p.flags) & STONK_EPI_SAVE_PREACT) ? 32 : 16) : (OUT_MODE == 1 ? 32 : 0);
+  auto wait_keep = [&](bool plus4) {   // at most S (+4) youngest operations may stay outstanding
+    if (S == 16) { if (plus4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+    else if (S == 32) { if (plus4) asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }
+    else { if (plus4) wait_vm4(); else wait_vm0(); }
+  };
+  int mode = 0;           // 0 steady state, 1 / 2 = first / second K tile after a tile boundary
+  bool ahead = false;     // mode 1: the K tile after this one was issued at the boundary
   for (;;) {      // one output tile (work item) per iteration; the DMA stream runs across iterations
     for (int ck = 0; ck < cw.nk; ++ck) {
       const int nb = buf ^ 1;
+      const bool do_issue = p_valid && mode != 1;
       // ---------------- phase 0: quadrant (A0, B0)
       read_a(buf, SLOT_A0);
-      read_b(buf, SLOT_B0);
-      if (p_valid) issue(SLOT_A0, nb);
-      if (!fresh) { if (p_valid) wait_vm4(); else wait_vm0(); }                // retires B-second of this K tile
+      read_b(buf, SLOT_B0, fb0);
+      if (do_issue) issue(SLOT_A0, nb);
+      if (mode == 0) { if (do_issue) wait_vm4(); else wait_vm0(); }            // retires B-second of this K tile
+      else if (mode == 2) wait_keep(do_issue);
       barrier();
       wait_lgkm0();
       __builtin_amdgcn_sched_barrier(0);
-      mma(acc[0][0]);
+      mma(acc[0][0], fb0);
       barrier();
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- phase 1: quadrant (A0, B1)
-      read_b(buf, SLOT_B1);
-      if (p_valid) issue(SLOT_B0, nb);
-      if (!fresh) { if (p_valid) wait_vm4(); else wait_vm0(); }                // retires A-second of this K tile
+      read_b(buf, SLOT_B1, fb1);
+      if (do_issue) issue(SLOT_B0, nb);
+      if (mode == 0) { if (do_issue) wait_vm4(); else wait_vm0(); }            // retires A-second of this K tile
+      else if (mode == 2) wait_keep(do_issue);
       barrier();
       wait_lgkm0();
       __builtin_amdgcn_sched_barrier(0);
-      mma(acc[0][1]);
+      mma(acc[0][1], fb1);
       barrier();
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- phase 2: quadrant (A1, B1)
       read_a(buf, SLOT_A1);   // B1 fragments are still in registers
-      if (p_valid) issue(SLOT_B1, nb);
+      if (do_issue) issue(SLOT_B1, nb);
       barrier();
       wait_lgkm0();
       __builtin_amdgcn_sched_barrier(0);
-      mma(acc[1][1]);
+      mma(acc[1][1], fb1);
       barrier();
       __builtin_amdgcn_sched_barrier(0);
-      // ---------------- phase 3: quadrant (A1, B0)
-      read_b(buf, SLOT_B0);   // re-read (16 VGPRs cheaper than keeping B0 live through all four phases)
-      if (p_valid) issue(SLOT_A1, nb);
-      const bool issued = p_valid;
-      if (issued) { wait_vm4(); } else { wait_vm0(); }                          // retires A-first, B-first of the next K tile
-      barrier();
-      wait_lgkm0();
-      __builtin_amdgcn_sched_barrier(0);
-      mma(acc[1][0]);
+      // ---------------- phase 3: quadrant (A1, B0): B0 fragments kept since phase 0 - no LDS read here, so a stage is
+      // read for the last time in phase 2 and may be re-staged right at the tile boundary
+      if (do_issue) issue(SLOT_A1, nb);
+      if (mode == 1) { if (ahead) wait_keep(true); }                             // retires A-first, B-first of the next K tile
+      else if (do_issue) wait_vm4();
+      else wait_vm0();
       barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (issued) advance_prefetch();
+      mma(acc[1][0], fb0);
+      barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (do_issue) advance_prefetch();
       buf = nb;
-      fresh = false;
+      mode = (mode == 1) ? 2 : 0;
     }
-    wait_vm0();   // B-second / A-second of the next K tile: land them BEFORE the stores enter the vmcnt queue
-    store_tile(cw);
-    fresh = true;
+    // ---- tile boundary: stage buf^1 (the K tile just finished) is free, stage buf holds the next K tile
+    Work nw;
     bool more;
     do {
       cwi += G;
-      more = get_work(cwi, cw);
-    } while (more && cw.nk <= 0);
+      more = get_work(cwi, nw);
+    } while (more && nw.nk <= 0);
+    if (more) load_bias_quads(nw);   // ahead of everything the boundary issues
+    ahead = p_valid;
+    if (ahead) {   // E1
+      issue(SLOT_A0, buf ^ 1);
+      issue(SLOT_B0, buf ^ 1);
+      issue(SLOT_B1, buf ^ 1);
+      issue(SLOT_A1, buf ^ 1);
+      advance_prefetch();
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // E2: everything older than those 8 DMA has landed
+    } else {
+      wait_vm0();
+    }
+    store_tile(cw);   // E3
+    mode = 1;
     if (!more) break;
-    zero_acc();
+    cw = nw;
+    init_acc();
   }
   if (wr == 0) barrier();   // balance the stagger barrier
 }
 
 }  // namespace
 
+namespace {
+template <int OUT_MODE, int EPI>
+int launch256(const GemmArgs& a, int grid, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel<OUT_MODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm256_kernel<OUT_MODE, EPI>), dim3(grid), dim3(512), LDS_BYTES, st, a);
+  return stonk_launch_status();
+}
+}  // namespace
+
 int stonk_gemm256_launch(const GemmArgs& a, int out_mode, hipStream_t st) {
-  static bool attr_done[3] = {false, false, false};
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -383,18 +439,20 @@ int stonk_gemm256_launch(const GemmArgs& a, int out_mode, hipStream_t st) {
   }
   const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.split_k;
   const int grid = (int)(tiles < n_cu ? tiles : n_cu);
-#define LAUNCH256(MODE)                                                                                         \
-  do {                                                                                                          \
-    if (!attr_done[MODE]) {                                                                                     \
-      (void)hipFuncSetAttribute((const void*)gemm256_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                LDS_BYTES);                                                                     \
-      attr_done[MODE] = true;                                                                                   \
-    }                                                                                                           \
-    hipLaunchKernelGGL((gemm256_kernel<MODE>), dim3(grid), dim3(512), LDS_BYTES, st, a);                        \
-  } while (0)
-  if (out_mode == 0) LAUNCH256(0);
-  else if (out_mode == 1) LAUNCH256(1);
-  else LAUNCH256(2);
-#undef LAUNCH256
-  return stonk_launch_status();
+  constexpr int B = STONK_EPI_BIAS, G = STONK_EPI_GELU, SV = STONK_EPI_SAVE_PREACT, GB = STONK_EPI_GELU_BWD,
+                R = STONK_EPI_RESID, D = STONK_EPI_DROPOUT;
+  const int epi = a.flags & (B | G | SV | GB | R | D);
+  if (out_mode == 1) return epi == 0 ? launch256<1, 0>(a, grid, st) : launch256<1, -1>(a, grid, st);
+  if (out_mode == 2) return launch256<2, 0>(a, grid, st);
+  switch (epi) {   // the combinations the STonKGs step uses are compiled with constant flags
+    case 0: return launch256<0, 0>(a, grid, st);
+    case B: return launch256<0, B>(a, grid, st);
+    case B | G: return launch256<0, B | G>(a, grid, st);
+    case B | G | SV: return launch256<0, B | G | SV>(a, grid, st);
+    case GB: return launch256<0, GB>(a, grid, st);
+    case R: return launch256<0, R>(a, grid, st);
+    case B | R: return launch256<0, B | R>(a, grid, st);
+    case B | R | D: return launch256<0, B | R | D>(a, grid, st);
+    default: return launch256<0, -1>(a, grid, st);
+  }
 }

@@ -254,10 +254,11 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   // halved operand traffic per flop outweighs one-workgroup-per-CU epilogues); N = 768 quantises badly (3 column tiles)
   // ... and epilogues that READ a second [M,N] operand (residual, saved pre-activation) still favour two co-resident
   // workgroups per CU hiding each other's load latency (tools/bench_epilogue.py)
-  const bool big = M >= 1024 && N >= 1536 && out_mode != STONK_EPI_OUT_F32_ATOMIC &&
+  const bool big = M >= 1024 && N >= 768 && out_mode != STONK_EPI_OUT_F32_ATOMIC &&
                    !(flags & (STONK_EPI_GELU_BWD | STONK_EPI_RESID));
   // its epilogue moves 16-byte row segments: strides of every side operand must keep them aligned
-  const bool v2_ok = ldc % 8 == 0 && (!(flags & STONK_EPI_RESID) || (ldr % 8 == 0 && (uintptr_t)resid % 16 == 0)) &&
+  const bool v2_ok = ldc % 8 == 0 && (!(flags & STONK_EPI_BIAS) || alpha == 1.0f) &&  // bias rides in the accumulators
+                      (!(flags & STONK_EPI_RESID) || (ldr % 8 == 0 && (uintptr_t)resid % 16 == 0)) &&
                      (!(flags & (STONK_EPI_SAVE_PREACT | STONK_EPI_GELU_BWD)) ||
                       (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0));
   if (v2_ok && !(flags & (STONK_EPI_DEBUG_V1 | STONK_EPI_DEBUG_REGSTAGE)) && (big || (flags & STONK_EPI_DEBUG_V2)))

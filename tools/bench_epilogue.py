@@ -17,7 +17,7 @@ for M, N, K in [(32768, 3072, 768), (32768, 768, 3072), (32768, 768, 768)]:
     aux = torch.randn(M, N, device="cuda").to(torch.bfloat16)
     res = torch.randn(M, N, device="cuda").to(torch.bfloat16)
     bias = torch.randn(N, device="cuda")
-    cases = {"plain": 0, "bias": hip.EPI_BIAS, "bias+gelu+save": hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT,
+    cases = {"plain": 0,  "bias": hip.EPI_BIAS, "bias+gelu+save": hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT,
              "gelu_bwd": hip.EPI_GELU_BWD, "bias+resid": hip.EPI_BIAS | hip.EPI_RESID,
              "bias+drop+resid": hip.EPI_BIAS | hip.EPI_RESID | hip.EPI_DROPOUT}
     for kname, dbg in (("v1", hip.EPI_DEBUG_V1), ("v2", hip.EPI_DEBUG_V2)):

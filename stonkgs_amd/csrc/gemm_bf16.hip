@@ -27,7 +27,10 @@ constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
 constexpr int GEMM_LDS = 2 * STAGE_BYTES;      // double buffered: 64 KiB
 
-template <int OUT_MODE, bool GLDS>
+// EPI >= 0: epilogue flags known at compile time (the combinations the STonKGs step launches): no dead branches, and
+// the side operands of a whole 64x64 wave tile are fetched in one batch BEFORE any of them is used, so their latency is
+// paid once per tile instead of once per fragment. EPI < 0: flags read at run time.
+template <int OUT_MODE, bool GLDS, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
     }
 
     // ---------------- epilogue (straight from the accumulators) ----------------
-    const int flags = p.flags;
+    const int flags = EPI >= 0 ? EPI : p.flags;
     if (OUT_MODE == 2) {
       // standard orientation: acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane>>4)*4 + r][n0 + wn*64 + j*16 + (lane&15)]
       float* C = (float*)p.C;
@@ -184,8 +187,67 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
             }
           }
         }
-    } else {
+    } else if (EPI >= 0) {
       // swapped: acc[i][j][r] = C[m0 + wm*64 + i*16 + (lane&15)][n0 + wn*64 + j*16 + (lane>>4)*4 + r]
+      const int nq = n0 + wn * 64 + (lane >> 4) * 4;
+      const int mq = m0 + wm * 64 + (lane & 15);
+      f32x4 bq[4];
+      bf16x4 sa[4][4], sr[4][4];
+      if (EPI & STONK_EPI_BIAS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bq[j] = *(const f32x4*)(p.bias + nq + j * 16);
+      }
+      if (EPI & (STONK_EPI_GELU_BWD | STONK_EPI_RESID)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int m = mq + i * 16;
+          m = m < M ? m : M - 1;   // clamped rows are loaded but never stored
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (EPI & STONK_EPI_GELU_BWD) sa[i][j] = *(const bf16x4*)(p.aux + (long)m * p.ldaux + nq + j * 16);
+            if (EPI & STONK_EPI_RESID) sr[i][j] = *(const bf16x4*)(p.resid + (long)m * p.ldr + nq + j * 16);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mq + i * 16;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = nq + j * 16;
+          f32x4 v = acc[i][j] * p.alpha;
+          if (EPI & STONK_EPI_BIAS) v += bq[j];
+          if (EPI & STONK_EPI_SAVE_PREACT) {
+            bf16x4 u = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *(bf16x4*)(p.aux + (long)m * p.ldaux + n) = u;
+          }
+          if (EPI & STONK_EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+          }
+          if (EPI & STONK_EPI_GELU_BWD) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)sa[i][j][r]);
+          }
+          if (EPI & STONK_EPI_DROPOUT) {
+            const uint32_t e = (uint32_t)((long)m * p.N + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = stonk_keep(e + r, p.seed, p.drop_thr24) ? v[r] * p.drop_scale : 0.f;
+          }
+          if (EPI & STONK_EPI_RESID) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)sr[i][j][r];
+          }
+          if (OUT_MODE == 0) {
+            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+          } else {
+            *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
+          }
+        }
+      }
+    } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + (lane & 15);
@@ -206,15 +268,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
   }
 }
 
-template <int OUT_MODE, bool GLDS>
+template <int OUT_MODE, bool GLDS, int EPI>
 int launch(const GemmArgs& a, int grid, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<OUT_MODE, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        GEMM_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<OUT_MODE, GLDS, EPI>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<OUT_MODE, GLDS>), dim3(grid), dim3(256), GEMM_LDS, st, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<OUT_MODE, GLDS, EPI>), dim3(grid), dim3(256), GEMM_LDS, st, a);
   return stonk_launch_status();
 }
 
@@ -254,7 +316,7 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   // halved operand traffic per flop outweighs one-workgroup-per-CU epilogues); N = 768 quantises badly (3 column tiles)
   // ... and epilogues that READ a second [M,N] operand (residual, saved pre-activation) still favour two co-resident
   // workgroups per CU hiding each other's load latency (tools/bench_epilogue.py)
-  const bool big = M >= 1024 && N >= 768 && out_mode != STONK_EPI_OUT_F32_ATOMIC &&
+  const bool big = M >= 1024 && N >= 1536 && out_mode != STONK_EPI_OUT_F32_ATOMIC &&
                    !(flags & (STONK_EPI_GELU_BWD | STONK_EPI_RESID));
   // its epilogue moves 16-byte row segments: strides of every side operand must keep them aligned
   const bool v2_ok = ldc % 8 == 0 && (!(flags & STONK_EPI_BIAS) || alpha == 1.0f) &&  // bias rides in the accumulators
@@ -268,10 +330,27 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   const long cap = m_dev ? 4096 : tiles;
   const int grid = (int)(tiles < cap ? tiles : cap);
   const bool glds = !(flags & STONK_EPI_DEBUG_REGSTAGE);
-  switch (out_mode) {
-    case STONK_EPI_OUT_BF16: return glds ? launch<0, true>(a, grid, st) : launch<0, false>(a, grid, st);
-    case STONK_EPI_OUT_F32: return glds ? launch<1, true>(a, grid, st) : launch<1, false>(a, grid, st);
-    default: return glds ? launch<2, true>(a, grid, st) : launch<2, false>(a, grid, st);
+  constexpr int Bi = STONK_EPI_BIAS, G = STONK_EPI_GELU, SV = STONK_EPI_SAVE_PREACT, GB = STONK_EPI_GELU_BWD,
+                R = STONK_EPI_RESID, D = STONK_EPI_DROPOUT;
+  const int epi = flags & (Bi | G | SV | GB | R | D);
+  if (!glds) {
+    switch (out_mode) {
+      case STONK_EPI_OUT_BF16: return launch<0, false, -1>(a, grid, st);
+      case STONK_EPI_OUT_F32: return launch<1, false, -1>(a, grid, st);
+      default: return launch<2, false, -1>(a, grid, st);
+    }
+  }
+  if (out_mode == STONK_EPI_OUT_F32_ATOMIC) return launch<2, true, -1>(a, grid, st);
+  if (out_mode == STONK_EPI_OUT_F32) return epi == 0 ? launch<1, true, 0>(a, grid, st) : launch<1, true, -1>(a, grid, st);
+  switch (epi) {
+    case 0: return launch<0, true, 0>(a, grid, st);
+    case Bi: return launch<0, true, Bi>(a, grid, st);
+    case Bi | G | SV: return launch<0, true, Bi | G | SV>(a, grid, st);
+    case GB: return launch<0, true, GB>(a, grid, st);
+    case R: return launch<0, true, R>(a, grid, st);
+    case Bi | R: return launch<0, true, Bi | R>(a, grid, st);
+    case Bi | R | D: return launch<0, true, Bi | R | D>(a, grid, st);
+    default: return launch<0, true, -1>(a, grid, st);
   }
 }
 

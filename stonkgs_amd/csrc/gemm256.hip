@@ -49,7 +49,13 @@ struct Work {
 // EPI >= 0: the epilogue flags are a compile-time constant (no dead side-operand loads for the compiler to guard with
 // vmcnt(0) - such a wait inside the epilogue rounds also waits for the previous round's STORES and costs ~2 us per
 // round); EPI < 0: flags read from the arguments at run time (rare combinations).
-template <int OUT_MODE, int EPI>
+//
+// TN = true: the weight-gradient form. A = dY [K tokens][M features], B = X [K tokens][N features] (both row-major as
+// backward holds them), C[M][N] += sum_t A[t][m] B[t][n], bias[m] += sum_t A[t][m]. Same schedule, same half-tile
+// cut; only the DMA source addressing (a half-tile image is [64 tokens][256 B]) and the fragment reads
+// (ds_read_b64_tr_b16 pairs, image swizzle c ^ (((r&3)<<2)|((r>>2)&3))) differ. 256x256 tiles halve the operand bytes
+// per flop against the 128x128 TN kernel, which runs at the L2's pace on the small weights of this model.
+template <int OUT_MODE, int EPI, bool TN>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   }
   const int N = p.N;
   const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
-  int nk_total = p.K / BK;
+  int nk_total = TN ? (p.K + BK - 1) / BK : p.K / BK;
   if (p.k_dev) {
     const int kd = (*p.k_dev + BK - 1) / BK;
     nk_total = kd < nk_total ? kd : nk_total;
@@ -111,12 +117,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   auto set_sources = [&](const Work& w) {
     p_m0 = w.m0;
     p_n0 = w.n0;
-    pk_bytes = w.k_begin * 2;
+    pk_bytes = TN ? w.k_begin : w.k_begin * 2;
   };
   // issue half-tile `slot` of the K tile at the prefetch cursor into stage `buf`
   auto issue = [&](int slot, int buf) {
     char* dst = smem + buf * STAGE_BYTES + slot * HALF_BYTES + wave * 2048;
     const bool isA = (slot == SLOT_A0 || slot == SLOT_A1);
+    if (TN) {
+      // image [64 token rows][256 B]; a wave-instruction = 4 rows; lane -> row (lane>>4), physical chunk (lane&15)
+      const char* base = (const char*)(isA ? p.A : p.B);
+      const long ld2 = (isA ? p.lda : p.ldb) * 2;
+      int lv = lane;
+      asm volatile("" : "+v"(lv));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 4 + (lv >> 4);
+        const int c = (lv & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));   // logical chunk for physical slot (lane & 15)
+        int feat;
+        if (isA) feat = p_m0 + (c >> 3) * 128 + (c & 7) * 8 + (slot == SLOT_A1 ? 64 : 0);
+        else feat = p_n0 + (c >> 2) * 64 + (c & 3) * 8 + (slot == SLOT_B1 ? 32 : 0);
+        const int lim = (isA ? M : N) - 8;
+        feat = feat < lim ? feat : lim;   // columns past the matrix: valid memory, results never stored
+        const long tok = pk_bytes + r;    // (token index of the K tile's first row is kept in pk_bytes for TN)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + tok * ld2 + feat * 2),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      }
+      return;
+    }
     const char* base = (const char*)(isA ? p.A : p.B) + pk_bytes;
     const long ld2 = (isA ? p.lda : p.ldb) * 2;
     const int lim = (isA ? M : N) - 1;
@@ -170,7 +197,36 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
           for (int j = 0; j < 2; ++j) acc[a][b][i][j] = bq[b][j];
   };
   bf16x8 fa[2][4], fb0[2][2], fb1[2][2];  // [k-step][tile]
+  // TN: transposed-read offsets. Lane (g = lane>>4, q = (lane&15)>>2, pq = lane&3) addresses token row 8g + 4hi + q
+  // (+32 per k-step: swizzle unchanged), 4 features at 4*pq of a 16-feature tile; it receives feature (lane&15).
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  int toffa[2][4], toffb[2][2];
+  if (TN) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+      const int row = 8 * g + 4 * hi + q;
+      const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) toffa[hi][i] = row * 256 + (((wr * 8 + 2 * i + (pq >> 1)) ^ sw) << 4) + ((pq & 1) << 3);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) toffb[hi][j] = row * 256 + (((wc * 4 + 2 * j + (pq >> 1)) ^ sw) << 4) + ((pq & 1) << 3);
+    }
+  }
+  auto tr_pair = [&](const char* s, int off_lo, int off_hi) -> bf16x8 {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(s + off_lo));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(s + off_hi));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
   auto read_a = [&](int buf, int slot) {
+    if (TN) {
+      const char* s = smem + buf * STAGE_BYTES + slot * HALF_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[ks][i] = tr_pair(s + ks * 8192, toffa[0][i], toffa[1][i]);
+      return;
+    }
     const char* s = smem + buf * STAGE_BYTES + slot * HALF_BYTES + a_row0 + frag_off;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -178,11 +234,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
       for (int i = 0; i < 4; ++i) fa[ks][i] = *(const bf16x8*)(s + i * 2048 + (((ks * 4 + kc) ^ swz) << 4));
   };
   auto read_b = [&](int buf, int slot, bf16x8 (&fb)[2][2]) {
+    if (TN) {
+      const char* s = smem + buf * STAGE_BYTES + slot * HALF_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[ks][j] = tr_pair(s + ks * 8192, toffb[0][j], toffb[1][j]);
+      return;
+    }
     const char* s = smem + buf * STAGE_BYTES + slot * HALF_BYTES + b_row0 + frag_off;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int j = 0; j < 2; ++j) fb[ks][j] = *(const bf16x8*)(s + j * 2048 + (((ks * 4 + kc) ^ swz) << 4));
+  };
+  // TN bias gradient: column sums of the A operand on the matrix pipe. One accumulator per A sub-block: fragment
+  // tile i is multiplied by a selector whose rows 4i..4i+3 are ones, so its sums land in the lanes with lane>>4 == i.
+  f32x4 accb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  auto bias_mma = [&](int a) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool on = ((lane & 15) >> 2) == i;
+      bf16x8 sel;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sel[e] = on ? (bf16)1.0f : (bf16)0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, fa[ks][i], accb[a], 0, 0, 0);
+    }
   };
   auto mma = [&](f32x4 (&c)[4][2], const bf16x8 (&fb)[2][2]) {
     __builtin_amdgcn_s_setprio(1);
@@ -296,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // advance the prefetch cursor by one K tile (after its 4 half-tiles have been issued)
   auto advance_prefetch = [&]() {
     ++pk;
-    pk_bytes += BK * 2;
+    pk_bytes += TN ? BK : BK * 2;
     if (pk >= pw.nk) {
       do {
         pwi += G;
@@ -319,6 +397,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   barrier();
   if (wr == 1) barrier();   // second wave-row runs one barrier behind
 
+  // TN: the first column tile's wave-column 0 also produces the bias gradient of its 128 features
+  bool want_bias = TN && p.bias != nullptr && cw.n0 == 0 && wc == 0;
   int buf = 0;    // stage holding the compute K tile
   // ---- tile boundary protocol. vmcnt retires in issue order, so a DMA wait placed AFTER the epilogue's stores in
   // program order would also wait for those stores (128 KiB per workgroup draining at the store path's pace). The
@@ -359,6 +439,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
       wait_lgkm0();
       __builtin_amdgcn_sched_barrier(0);
       mma(acc[0][1], fb1);
+      if (TN && want_bias) bias_mma(0);
       barrier();
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- phase 2: quadrant (A1, B1)
@@ -372,13 +453,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- phase 3: quadrant (A1, B0): B0 fragments kept since phase 0 - no LDS read here, so a stage is
       // read for the last time in phase 2 and may be re-staged right at the tile boundary
+      if (TN) read_b(buf, SLOT_B0, fb0);   // TN keeps no B0 fragments across phases 1-2 (register budget); it also
+                                           // skips the boundary's early re-staging, so this late read is safe
       if (do_issue) issue(SLOT_A1, nb);
       if (mode == 1) { if (ahead) wait_keep(true); }                             // retires A-first, B-first of the next K tile
       else if (do_issue) wait_vm4();
       else wait_vm0();
       barrier();
+      if (TN) wait_lgkm0();
       __builtin_amdgcn_sched_barrier(0);
       mma(acc[1][0], fb0);
+      if (TN && want_bias) bias_mma(1);
       barrier();
       __builtin_amdgcn_sched_barrier(0);
       if (do_issue) advance_prefetch();
@@ -393,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
       more = get_work(cwi, nw);
     } while (more && nw.nk <= 0);
     if (more) load_bias_quads(nw);   // ahead of everything the boundary issues
-    ahead = p_valid;
+    ahead = p_valid && !TN;
     if (ahead) {   // E1
       issue(SLOT_A0, buf ^ 1);
       issue(SLOT_B0, buf ^ 1);
@@ -405,9 +490,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
       wait_vm0();
     }
     store_tile(cw);   // E3
-    mode = 1;
+    if (TN && want_bias) {   // lanes with lane>>4 == i hold the column sums of feature tile i (all four registers equal)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int m = cw.m0 + wr * 128 + a * 64 + (lane >> 4) * 16 + (lane & 15);
+        if (m < M) atomicAdd((float*)p.bias + m, accb[a][0] * p.alpha);
+        accb[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    mode = TN ? 0 : 1;
     if (!more) break;
     cw = nw;
+    want_bias = TN && p.bias != nullptr && cw.n0 == 0 && wc == 0;
     init_acc();
   }
   if (wr == 0) barrier();   // balance the stagger barrier
@@ -416,18 +510,38 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 }  // namespace
 
 namespace {
-template <int OUT_MODE, int EPI>
+template <int OUT_MODE, int EPI, bool TN = false>
 int launch256(const GemmArgs& a, int grid, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm256_kernel<OUT_MODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel<OUT_MODE, EPI, TN>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm256_kernel<OUT_MODE, EPI>), dim3(grid), dim3(512), LDS_BYTES, st, a);
+  hipLaunchKernelGGL((gemm256_kernel<OUT_MODE, EPI, TN>), dim3(grid), dim3(512), LDS_BYTES, st, a);
   return stonk_launch_status();
 }
 }  // namespace
+
+static int cu_count() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    n_cu = prop.multiProcessorCount;
+  }
+  return n_cu;
+}
+
+// weight-gradient form (see gemm_tn.hip for the contract): C fp32 [M,N] += alpha * A[K,M]^T . B[K,N], bias[M] += colsum
+int stonk_gemm256_tn_launch(const GemmArgs& a, hipStream_t st) {
+  const int n_cu = cu_count();
+  if (n_cu <= 0) return (int)hipGetLastError();
+  const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.split_k;
+  const int grid = (int)(tiles < n_cu ? tiles : n_cu);
+  return launch256<2, 0, true>(a, grid, st);
+}
 
 int stonk_gemm256_launch(const GemmArgs& a, int out_mode, hipStream_t st) {
   static int n_cu = 0;

@@ -168,3 +168,43 @@ def test_gemm_tn_asymmetric_and_device_token_count(hip):
     hip.call("stonk_gemm_tn_bf16", hip.ptr(dY2), Mo, hip.ptr(X2), No, hip.ptr(dW2), No, 0, Mo, No, T, 1.0, 1,
              hip.ptr(k_dev), hip.stream_ptr())
     torch.testing.assert_close(dW2, dY2[:k].float().t() @ X2[:k].float(), rtol=1e-4, atol=1e-3)
+
+
+def test_gemm_tn_256_exact_and_matches_small_kernel(hip):
+    """The persistent 256x256 weight-gradient kernel: exact integer data (any fragment / swizzle / half-tile mix-up
+    shows), bias sums through the selector MFMA, agreement with the 128x128 kernel, bitwise-stable repeats."""
+    T, Mo, No = 2048, 768, 1024
+    dY = torch.zeros(T, Mo, device="cuda", dtype=torch.bfloat16)
+    dY[torch.arange(T), (torch.arange(T) * 7) % Mo] = 1.0
+    dY[torch.arange(T), (torch.arange(T) * 13 + 5) % Mo] += 2.0
+    X = ((torch.arange(T * No, device="cuda").reshape(T, No) % 61) - 30).to(torch.bfloat16)
+    dW = torch.zeros(Mo, No, device="cuda")
+    db = torch.zeros(Mo, device="cuda")
+    hip.call("stonk_gemm_tn_bf16", hip.ptr(dY), Mo, hip.ptr(X), No, hip.ptr(dW), No, hip.ptr(db), Mo, No, T, 1.0, 0, 0,
+             hip.stream_ptr())
+    assert torch.equal(dW, dY.float().t() @ X.float())
+    assert torch.equal(db, dY.float().sum(0))
+    # random data: 256x256 path vs forced 128x128 path vs torch
+    T, Mo, No = 16384, 3072, 768
+    dY, X = _rand((T, Mo), 0.5, 41), _rand((T, No), 0.5, 42)
+    ref = dY.float().t() @ X.float()
+    outs = []
+    for sk in (0, 4):
+        dW = torch.zeros(Mo, No, device="cuda")
+        db = torch.zeros(Mo, device="cuda")
+        hip.call("stonk_gemm_tn_bf16", hip.ptr(dY), Mo, hip.ptr(X), No, hip.ptr(dW), No, hip.ptr(db), Mo, No, T, 1.0, sk,
+                 0, hip.stream_ptr())
+        torch.testing.assert_close(dW, ref, rtol=1e-4, atol=8e-3)
+        torch.testing.assert_close(db, dY.float().sum(0), rtol=1e-4, atol=8e-3)
+        outs.append(dW)
+    # odd feature counts (decoder: 29056 = 113.5 x 256) and a device-side token count
+    T, Mo, No = 4096, 29056, 512
+    dY, X = _rand((T, Mo), 0.5, 43), _rand((T, No), 0.5, 44)
+    k = 2432
+    dY[k:2496] = 0
+    X[k:2496] = 0
+    k_dev = torch.tensor([k], device="cuda", dtype=torch.int32)
+    dW = torch.zeros(Mo, No, device="cuda")
+    hip.call("stonk_gemm_tn_bf16", hip.ptr(dY), Mo, hip.ptr(X), No, hip.ptr(dW), No, 0, Mo, No, T, 1.0, 0,
+             hip.ptr(k_dev), hip.stream_ptr())
+    torch.testing.assert_close(dW, dY[:k].float().t() @ X[:k].float(), rtol=1e-4, atol=4e-3)

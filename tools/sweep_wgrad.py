@@ -1,4 +1,4 @@
-"""Split-K sweep for the wgrad-shaped GEMMs of the step (development aid)."""
+"""Weight-gradient (TN) kernels on the shapes of the step: 128x128 tiles (forced, split sweep) vs persistent 256x256."""
 import os
 import sys
 
@@ -10,15 +10,16 @@ from stonkgs_amd import _hip as hip  # noqa: E402
 from bench_kernels import timeit  # noqa: E402
 
 hip.lib()
-K = 32768
+T = 32768
 for Mo, No in [(768, 768), (2304, 768), (3072, 768), (768, 3072)]:
-    A = torch.randn(Mo, K, device="cuda").to(torch.bfloat16)
-    B = torch.randn(No, K, device="cuda").to(torch.bfloat16)
-    C = torch.zeros(Mo, No, device="cuda")
-    for name, dbg in (("v1", hip.EPI_DEBUG_V1), ("v2", hip.EPI_DEBUG_V2)):
-        for sk in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
-            def f():
-                hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), No, Mo, No, K,
-                         hip.EPI_OUT_F32_ATOMIC | dbg, 0, 0, 0, 0, 0, 1.0, sk, 0, 0, 0.0, 0, hip.stream_ptr())
-            t = timeit(f, iters=10)
-            print(f"wgrad {Mo}x{No} {name} split={sk}: {t*1e6:.1f} us {2*Mo*No*K/t/1e12:.0f} TF/s", flush=True)
+    dY = torch.randn(T, Mo, device="cuda").to(torch.bfloat16)
+    X = torch.randn(T, No, device="cuda").to(torch.bfloat16)
+    dW = torch.zeros(Mo, No, device="cuda")
+    db = torch.zeros(Mo, device="cuda")
+    for sk in (3, 4, 6, 12, 0):
+        def f():
+            hip.call("stonk_gemm_tn_bf16", hip.ptr(dY), Mo, hip.ptr(X), No, hip.ptr(dW), No, hip.ptr(db), Mo, No, T, 1.0,
+                     sk, 0, hip.stream_ptr())
+        t = timeit(f, iters=10)
+        name = f"128x128 split={sk}" if sk > 0 else "256x256 auto"
+        print(f"wgrad_tn {Mo}x{No} {name}: {t*1e6:.1f} us {2*Mo*No*T/t/1e12:.0f} TF/s", flush=True)

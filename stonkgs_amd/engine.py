@@ -30,21 +30,25 @@ class GemmTimer:
     """Optional per-launch HIP-event timing of the GEMM kernel (bench.py roofline leg)."""
 
     def __init__(self):
-        self.records = []  # (start_event, end_event, M, N, K, m_dev, k_dev)
+        self.records = []  # (kind, start_event, end_event, M, N, K, m_dev, k_dev)
 
-    def summarize(self):
+    def summarize(self, kind=None):
         """Algorithmic FLOPs use the rows / contraction length that exist at run time (device-side counts of the
-        label-sparse decoders), not the launch capacity."""
+        label-sparse decoders), not the launch capacity. kind: "tn" (weight-gradient kernel), "nt", or None = all."""
         torch.cuda.synchronize()
         tot_t = tot_f = 0.0
-        for s, e, M, N, K, m_dev, k_dev in self.records:
+        n = 0
+        for k, s, e, M, N, K, m_dev, k_dev in self.records:
+            if kind is not None and k != kind:
+                continue
+            n += 1
             tot_t += s.elapsed_time(e) * 1e-3
             if m_dev is not None:
                 M = min(M, int(m_dev.item()))
             if k_dev is not None:
                 K = min(K, int(k_dev.item()))
             tot_f += 2.0 * M * N * K
-        return {"launches": len(self.records), "seconds": tot_t, "flops": tot_f}
+        return {"launches": n, "seconds": tot_t, "flops": tot_f}
 
 
 class Engine:
@@ -98,7 +102,7 @@ class Engine:
                  seed & 0xFFFFFFFF, st)
         if timed:
             e1.record()
-            self.gemm_timer.records.append((e0, e1, M, N, K, m_dev, k_dev))
+            self.gemm_timer.records.append(("nt", e0, e1, M, N, K, m_dev, k_dev))
 
     @staticmethod
     def _split_k(M, N, K) -> int:
@@ -118,7 +122,7 @@ class Engine:
                  hip.stream_ptr())
         if timed:
             e1.record()
-            self.gemm_timer.records.append((e0, e1, M_out, N_in, T, None, k_dev))
+            self.gemm_timer.records.append(("tn", e0, e1, M_out, N_in, T, None, k_dev))
 
     def transpose(self, x, rows, cols, name, colsum=None, rows_dev=None):
         rpad = (rows + 63) // 64 * 64

@@ -281,6 +281,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // 16-byte-per-lane row segment (4 lanes = one 128-byte line) instead of 8-byte pieces scattered over 16 rows
   // (those cost more than the whole K loop at K = 768). Wave-private: no workgroup barrier, the DMA stream of the
   // next tile keeps running underneath.
+  // Side operand of the epilogue (residual OR saved pre-activation, never both on this kernel): the 16 row segments of
+  // this lane are requested in two batches of 8 - the first at the very top of the tile boundary, before the
+  // boundary's DMA, so that the boundary's own wait (E2) covers it; the second right after that wait, so it flies while
+  // rounds 0-3 are processed. Latency is paid about once per tile instead of once per 16-row round. The vectors live
+  // in registers the operand fragments have just vacated (8 x 4 VGPRs per batch).
+  constexpr int FL = EPI >= 0 ? EPI : 0;
+  constexpr bool HAS_SIDE = EPI >= 0 && (FL & (STONK_EPI_RESID | STONK_EPI_GELU_BWD)) != 0 && OUT_MODE != 2;
+  bf16x8 side_a[4][2], side_b[4][2];
+  auto prefetch_side = [&](const Work& w, int batch, bf16x8 (&dst)[4][2]) {
+    if (!HAS_SIDE) return;
+    const int n = w.n0 + wc * 64 + (lane & 7) * 8;
+    const int mbase = w.m0 + wr * 128 + batch * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int mm = mbase + i * 16 + h * 8 + (lane >> 3);
+        dst[i][h] = side_load1(p, FL, mm, n, mm < M && n < N);
+      }
+  };
   auto store_tile = [&](const Work& w) {
     char* ep = smem + LDS_STAGES + wave * 4096;
     const int flags = (EPI >= 0 ? EPI : p.flags) & ~STONK_EPI_BIAS;
@@ -292,8 +312,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     const int mbase = w.m0 + wr * 128;
     // (the bias is already inside the accumulators: they were INITIALISED with it, see init_acc)
     const f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-    SideOps side[2][2];   // [round parity][half]: residual / saved pre-activation, fetched one round ahead
-    if (OUT_MODE != 2) {
+    SideOps side[2][2];   // run-time-flag instance only: fetched one round ahead
+    if (OUT_MODE != 2 && !HAS_SIDE) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int mm = mbase + h * 8 + rrow;
@@ -304,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     for (int rd = 0; rd < 8; ++rd) {
       const int a = rd >> 2, i = rd & 3;
       const int m = mbase + a * 64 + i * 16;
-      if (OUT_MODE != 2 && rd + 1 < 8) {
+      if (OUT_MODE != 2 && !HAS_SIDE && rd + 1 < 8) {
         const int mnext = mbase + ((rd + 1) >> 2) * 64 + ((rd + 1) & 3) * 16;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -340,7 +360,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
           const int mm = m + h * 8 + rrow;
           if (mm < M && n_ok) {
             float v[8] = {q[h][0][0], q[h][0][1], q[h][0][2], q[h][0][3], q[h][1][0], q[h][1][1], q[h][1][2], q[h][1][3]};
-            epilogue8_pre(v, p, flags, mm, n, b0, b1, side[rd & 1][h]);
+            if (HAS_SIDE) {
+              SideOps so;
+              so.aux = so.res = (rd < 4) ? side_a[rd & 3][h] : side_b[rd & 3][h];
+              epilogue8_pre(v, p, flags, mm, n, b0, b1, so);
+            } else {
+              epilogue8_pre(v, p, flags, mm, n, b0, b1, side[rd & 1][h]);
+            }
             if (OUT_MODE == 0) {
               bf16x8 o;
 #pragma unroll
@@ -478,6 +504,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
       more = get_work(cwi, nw);
     } while (more && nw.nk <= 0);
     if (more) load_bias_quads(nw);   // ahead of everything the boundary issues
+    prefetch_side(cw, 0, side_a);
     ahead = p_valid && !TN;
     if (ahead) {   // E1
       issue(SLOT_A0, buf ^ 1);
@@ -489,6 +516,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     } else {
       wait_vm0();
     }
+    prefetch_side(cw, 1, side_b);
     store_tile(cw);   // E3
     if (TN && want_bias) {   // lanes with lane>>4 == i hold the column sums of feature tile i (all four registers equal)
 #pragma unroll
@@ -566,7 +594,6 @@ int stonk_gemm256_launch(const GemmArgs& a, int out_mode, hipStream_t st) {
     case GB: return launch256<0, GB>(a, grid, st);
     case R: return launch256<0, R>(a, grid, st);
     case B | R: return launch256<0, B | R>(a, grid, st);
-    case B | R | D: return launch256<0, B | R | D>(a, grid, st);
     default: return launch256<0, -1>(a, grid, st);
   }
 }

@@ -316,8 +316,11 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   // halved operand traffic per flop outweighs one-workgroup-per-CU epilogues); N = 768 quantises badly (3 column tiles)
   // ... and epilogues that READ a second [M,N] operand (residual, saved pre-activation) still favour two co-resident
   // workgroups per CU hiding each other's load latency (tools/bench_epilogue.py)
-  const bool big = M >= 1024 && N >= 1536 && out_mode != STONK_EPI_OUT_F32_ATOMIC &&
-                   !(flags & (STONK_EPI_GELU_BWD | STONK_EPI_RESID));
+  const bool both_sides = (flags & STONK_EPI_GELU_BWD) && (flags & STONK_EPI_RESID);
+  // (bias + dropout + residual has no constant-flag instance on the 256x256 kernel: it would spill)
+  const bool bdr = (flags & STONK_EPI_DROPOUT) && (flags & STONK_EPI_RESID);
+  const bool big = M >= 1024 && N >= 1536 && out_mode != STONK_EPI_OUT_F32_ATOMIC && !both_sides && !bdr &&
+                   !(flags & STONK_EPI_DEBUG_SIDE_V1);
   // its epilogue moves 16-byte row segments: strides of every side operand must keep them aligned
   const bool v2_ok = ldc % 8 == 0 && (!(flags & STONK_EPI_BIAS) || alpha == 1.0f) &&  // bias rides in the accumulators
                       (!(flags & STONK_EPI_RESID) || (ldr % 8 == 0 && (uintptr_t)resid % 16 == 0)) &&

@@ -111,6 +111,15 @@ __device__ __forceinline__ void side_prefetch(SideOps& s, const GemmArgs& p, int
   if (flags & STONK_EPI_GELU_BWD) s.aux = *(const bf16x8*)(p.aux + (long)m * p.ldaux + n);
   if (flags & STONK_EPI_RESID) s.res = *(const bf16x8*)(p.resid + (long)m * p.ldr + n);
 }
+// single-vector form for kernels that carry exactly one side operand (GELU' input OR residual)
+__device__ __forceinline__ bf16x8 side_load1(const GemmArgs& p, int flags, int m, int n, bool ok) {
+  bf16x8 z;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
+  if (!ok) return z;
+  if (flags & STONK_EPI_GELU_BWD) return *(const bf16x8*)(p.aux + (long)m * p.ldaux + n);
+  return *(const bf16x8*)(p.resid + (long)m * p.ldr + n);
+}
 // epilogue8 with preloaded bias (8 columns of this lane, fixed for the whole tile) and side operands
 __device__ __forceinline__ void epilogue8_pre(float (&v)[8], const GemmArgs& p, int flags, int m, int n, const f32x4& b0,
                                               const f32x4& b1, const SideOps& s) {

@@ -14,6 +14,7 @@
 #define STONK_EPI_DEBUG_REGSTAGE (1 << 16) /* A/B test: register staging instead of LDS-DMA (128x128 kernel) */
 #define STONK_EPI_DEBUG_V1 (1 << 17)       /* force the 128x128 two-barrier kernel */
 #define STONK_EPI_DEBUG_V2 (1 << 18)       /* force the persistent 256x256 kernel */
+#define STONK_EPI_DEBUG_SIDE_V1 (1 << 19)  /* A/B test: keep side-operand epilogues on the 128x128 kernel */
 // --- stonk_layernorm_* `flags` ---
 #define STONK_LN_DROPOUT (1 << 0)
 // --- stonk_small_linear_* `act` ---

@@ -66,6 +66,11 @@ class Engine:
         self.gemm_timer: Optional[GemmTimer] = None
         self.saved = None
         self.seed_base = 0x5710
+        # Weight-gradient GEMMs are off the critical path of backward (nothing downstream reads dW until the optimizer):
+        # they are launched on a second HIP stream and overlap the dgrad / LayerNorm / attention chain on the main one.
+        self.overlap_wgrad = True
+        self._wstream: Optional[torch.cuda.Stream] = None
+        self._wgrad_done: Dict[int, torch.cuda.Event] = {}   # layer parity -> side-stream event after its last wgrad
 
     # ------------------------------------------------------------------ plumbing
     def buf(self, name: str, shape, dtype=BF16, zero=False) -> torch.Tensor:
@@ -113,6 +118,17 @@ class Engine:
 
     def wgrad(self, dy, x, dW, db, M_out, N_in, T, k_dev=None, alpha=1.0):
         """dW[M_out, N_in] += dy[T, M_out]^T . x[T, N_in];  db[M_out] += colsum(dy)   (fp32 atomics, split-K)."""
+        if self.overlap_wgrad and self.gemm_timer is None:
+            if self._wstream is None:
+                self._wstream = torch.cuda.Stream(device=self.device)
+            ready = torch.cuda.Event()
+            ready.record()                       # dy (and x) are complete on the main stream at this point
+            self._wstream.wait_event(ready)
+            with torch.cuda.stream(self._wstream):
+                hip.call("stonk_gemm_tn_bf16", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(),
+                         dW.stride(0), hip.ptr(db), M_out, N_in, T, alpha, self._split_k(M_out, N_in, T), hip.ptr(k_dev),
+                         hip.stream_ptr())
+            return
         timed = self.gemm_timer is not None
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -209,9 +225,15 @@ class Engine:
         g_ = P.grad_view
         f = P.view
         wt = P.wt
+        # dY buffers alternate by layer parity: the side stream may still be reading layer i+1's while layer i writes;
+        # before reusing the buffers of layer i+2 the main stream waits for that layer's last weight-gradient GEMM
+        par = lidx & 1
+        ev = self._wgrad_done.pop(par, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
         # ---- LN2 backward: ds2 (residual branch) and df (through the FFN-output dropout)
-        ds2 = self.buf("b.ds2", (T, H))
-        df = self.buf("b.df", (T, H)) if p_hid > 0 else None
+        ds2 = self.buf(f"b.ds2.{par}", (T, H))
+        df = self.buf(f"b.df.{par}", (T, H)) if p_hid > 0 else None
         hip.call("stonk_layernorm_bwd", dy.data_ptr(), sv["s2"].data_ptr(), sv["st2"][0].data_ptr(),
                  sv["st2"][1].data_ptr(), f(prefix + ".output.LayerNorm.weight").data_ptr(), ds2.data_ptr(), hip.ptr(df),
                  g_(prefix + ".output.LayerNorm.weight").data_ptr(), g_(prefix + ".output.LayerNorm.bias").data_ptr(),
@@ -220,7 +242,7 @@ class Engine:
             df = ds2
         # ---- FFN down: wgrad, bias grad, dgrad fused with GELU'
         self.wgrad(df, sv["g"], g_(prefix + ".output.dense.weight"), g_(prefix + ".output.dense.bias"), H, I, T)
-        du = self.buf("b.du", (T, I))
+        du = self.buf(f"b.du.{par}", (T, I))
         self.gemm(df, wt[prefix + ".output.dense.weight"], du, T, I, H, flags=hip.EPI_GELU_BWD, aux=sv["u"])
         # ---- FFN up
         self.wgrad(du, sv["h1"], g_(prefix + ".intermediate.dense.weight"), g_(prefix + ".intermediate.dense.bias"), I, H,
@@ -228,8 +250,8 @@ class Engine:
         dh1 = self.buf("b.dh1", (T, H))
         self.gemm(du, wt[prefix + ".intermediate.dense.weight"], dh1, T, H, I, flags=hip.EPI_RESID, resid=ds2)
         # ---- LN1 backward
-        ds1 = self.buf("b.ds1", (T, H))
-        da = self.buf("b.da", (T, H)) if p_hid > 0 else None
+        ds1 = self.buf(f"b.ds1.{par}", (T, H))
+        da = self.buf(f"b.da.{par}", (T, H)) if p_hid > 0 else None
         hip.call("stonk_layernorm_bwd", dh1.data_ptr(), sv["s1"].data_ptr(), sv["st1"][0].data_ptr(),
                  sv["st1"][1].data_ptr(), f(prefix + ".attention.output.LayerNorm.weight").data_ptr(), ds1.data_ptr(),
                  hip.ptr(da), g_(prefix + ".attention.output.LayerNorm.weight").data_ptr(),
@@ -244,7 +266,7 @@ class Engine:
         self.gemm(da, wt[prefix + ".attention.output.dense.weight"], dctx, T, H, H)
         # ---- attention core
         qkv = sv["qkv"]
-        dqkv = self.buf("b.dqkv", (T, 3 * H))
+        dqkv = self.buf(f"b.dqkv.{par}", (T, 3 * H))
         delta = self.buf("b.delta", (B, NH, seq), F32)
         hip.call("stonk_attention_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H,
                  hip.ptr(mask), sv["ctx"].data_ptr(), H, dctx.data_ptr(), H, sv["lse"].data_ptr(), delta.data_ptr(),
@@ -255,6 +277,10 @@ class Engine:
                    3 * H, H, T)
         dx = self.buf(f"b.dx{lidx & 1}", (T, H))
         self.gemm(dqkv, wt[prefix + ".attention.self.qkv.weight"], dx, T, H, 3 * H, flags=hip.EPI_RESID, resid=ds1)
+        if self._wstream is not None and self.overlap_wgrad and self.gemm_timer is None:
+            done = torch.cuda.Event()
+            done.record(self._wstream)
+            self._wgrad_done[par] = done
         return dx
 
     # ------------------------------------------------------------------ frozen backbone
@@ -422,7 +448,7 @@ class Engine:
         P = self.P
         f, g_, wt = P.view, P.grad_view, P.wt
         cap = B * half
-        notify = on_segment_done or (lambda name: None)
+        notify = self._make_notify(on_segment_done)
         # ---- decoders (label-sparse): dHs = dlogits . W ; dW += dlogits^T . Hs
         dt = self.buf("b.dt", (T, H))
         dt.zero_()
@@ -461,6 +487,31 @@ class Engine:
                  g_("cls.seq_relationship.bias").data_ptr(), dpooled.data_ptr(), 0, 0, B, 2, H, hip.SMALL_X_F32, st)
         self.backward_encoder(dpooled, dseq, sv, notify)
 
+    def _make_notify(self, hook):
+        """Gradients of a segment are final once the SIDE stream has run its weight-gradient GEMMs: the DP hook (RCCL
+        all-reduce) is therefore issued under the side stream, which it then orders itself after."""
+        if hook is None:
+            return lambda name: None
+        if not self.overlap_wgrad:
+            return hook
+
+        def notify(name):
+            if self._wstream is None:
+                hook(name)
+                return
+            ready = torch.cuda.Event()
+            ready.record()                      # bias / LayerNorm gradients written by main-stream kernels
+            self._wstream.wait_event(ready)
+            with torch.cuda.stream(self._wstream):
+                hook(name)
+        return notify
+
+    def join_wgrad(self) -> None:
+        """Main stream waits for every outstanding weight-gradient GEMM (before the optimizer reads the gradients)."""
+        if self._wstream is not None:
+            torch.cuda.current_stream().wait_stream(self._wstream)
+        self._wgrad_done.clear()
+
     def backward_encoder(self, dpooled, dseq, sv, notify) -> None:
         """Pooler (tanh) backward into position 0 of d(sequence_output), encoder layers last to first, embeddings."""
         cfg = self.cfg
@@ -490,6 +541,7 @@ class Engine:
                  g_("bert.embeddings.position_embeddings.weight").data_ptr(),
                  g_("bert.embeddings.token_type_embeddings.weight").data_ptr(), B, S, H, cfg.type_vocab_size, st)
         notify("bert.embeddings")
+        self.join_wgrad()
 
     # ------------------------------------------------------------------ sequence classification head (config 5)
     def forward_cls(self, input_ids, attention_mask, token_type_ids, labels, num_labels: int, training: bool,
@@ -535,7 +587,7 @@ class Engine:
         B, C = sv["B"], sv["num_labels"]
         st = hip.stream_ptr()
         f, g_ = self.P.view, self.P.grad_view
-        notify = on_segment_done or (lambda name: None)
+        notify = self._make_notify(on_segment_done)
         dl = sv["dl"]
         if gscale != 1.0:
             hip.call("stonk_scale_f32", dl.data_ptr(), dl.numel(), gscale, st)

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const bf16* __restrict__ dy, const bf16* __restrict__ x, const float* __restrict__ mean_in,
     const float* __restrict__ rstd_in, const float* __restrict__ gamma, bf16* __restrict__ dx,
     bf16* __restrict__ dx_drop, float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int H, int flags,
-    uint32_t thr24_in, float dscale_in, uint32_t seed_in, uint32_t thr24_out, float dscale_out, uint32_t seed_out) {
+    uint32_t thr24_in, float dscale_in, uint32_t seed_in, uint32_t thr24_out, float dscale_out, uint32_t seed_out,
+    float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float sred[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = H >> 3;
@@ -169,11 +170,37 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < 8; ++j) ag[i][j] = ab[i][j] = 0.f;
 
-  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+  // software prefetch: the raw bf16 chunks of the NEXT row are requested before the current row is processed (16 extra
+  // VGPRs), so each wave keeps two rows' loads in flight instead of stalling a full memory latency per row
+  const long stride = (long)gridDim.x * 4;
+  long row = (long)blockIdx.x * 4 + wave;
+  bf16x8 nx[CPL], nd[CPL];
+  float nmean = 0.f, nrstd = 0.f;
+  auto fetch = [&](long r) {
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        nx[i] = *(const bf16x8*)(x + r * H + c * 8);
+        nd[i] = *(const bf16x8*)(dy + r * H + c * 8);
+      }
+    }
+    nmean = mean_in[r];
+    nrstd = rstd_in[r];
+  };
+  if (row < rows) fetch(row);
+  for (; row < rows; row += stride) {
     RowRegs<CPL> rx, rd;
-    load_bf16_row<CPL>(x + row * H, nch, lane, rx);
-    load_bf16_row<CPL>(dy + row * H, nch, lane, rd);
-    const float mean = mean_in[row], rstd = rstd_in[row];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = lane + 64 * i < nch;
+        rx.v[i][j] = ok ? (float)nx[i][j] : 0.f;
+        rd.v[i][j] = ok ? (float)nd[i][j] : 0.f;
+      }
+    const float mean = nmean, rstd = nrstd;
+    if (row + stride < rows) fetch(row + stride);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
@@ -233,10 +260,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     for (int col = threadIdx.x; col < H; col += 256) {
       const float g = sg[col] + sg[H + col] + sg[2 * H + col] + sg[3 * H + col];
       const float b = sb[col] + sb[H + col] + sb[2 * H + col] + sb[3 * H + col];
-      atomicAdd(dgamma + col, g);
-      atomicAdd(dbeta + col, b);
+      if (ws) {  // per-workgroup partials, summed by ln_partial_reduce_kernel: ~10^3 workgroups adding atomically into the
+                 // same 2H addresses run at the contended-atomic rate (the kernel spent more time there than streaming)
+        ws[(long)blockIdx.x * 2 * H + col] = g;
+        ws[(long)blockIdx.x * 2 * H + H + col] = b;
+      } else {
+        atomicAdd(dgamma + col, g);
+        atomicAdd(dbeta + col, b);
+      }
     }
   }
+}
+
+// dgamma[c] += sum_b ws[b][c], dbeta[c] += sum_b ws[b][H + c]: grid (2H/256, 32) - each workgroup sums 1/32 of the
+// partial rows for 256 columns (coalesced 1 KiB row segments), then 32 adders per address finish with atomics.
+__global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ ws, int nb, int H,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;   // 0 .. 2H-1
+  if (c >= 2 * H) return;
+  const int per = (nb + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per;
+  const int b1 = b0 + per < nb ? b0 + per : nb;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int b = b0;
+  for (; b + 4 <= b1; b += 4) {
+    a0 += ws[(long)b * 2 * H + c];
+    a1 += ws[(long)(b + 1) * 2 * H + c];
+    a2 += ws[(long)(b + 2) * 2 * H + c];
+    a3 += ws[(long)(b + 3) * 2 * H + c];
+  }
+  for (; b < b1; ++b) a0 += ws[(long)b * 2 * H + c];
+  const float s = (a0 + a1) + (a2 + a3);
+  if (b1 > b0) atomicAdd(c < H ? dgamma + c : dbeta + (c - H), s);
 }
 
 // K2+K3: gather / concat / position + token-type add / LayerNorm in one pass.
@@ -369,17 +424,24 @@ extern "C" int stonk_layernorm_fwd(const void* x, const float* gamma, const floa
 extern "C" int stonk_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd,
                                    const float* gamma, void* dx, void* dx_drop, float* dgamma, float* dbeta,
                                    int64_t rows, int H, int flags, float drop_p_in, uint32_t seed_in,
-                                   float drop_p_out, uint32_t seed_out, void* stream) {
+                                   float drop_p_out, uint32_t seed_out, float* partial_ws, int64_t ws_floats,
+                                   void* stream) {
   STONK_CHECK_ARG(dy && x && mean && rstd && gamma && dx, STONK_EINVAL);
   STONK_CHECK_ARG(rows >= 0 && H > 0 && H % 8 == 0 && H <= 4096, STONK_ESHAPE);
   STONK_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), STONK_EINVAL);
   if (rows == 0) return STONK_OK;
   const size_t lds = dgamma ? (size_t)8 * H * sizeof(float) : 0;
-  LN_DISPATCH(H, hipLaunchKernelGGL((layernorm_bwd_kernel<CPL>), dim3(ln_grid(rows) < 1024 ? ln_grid(rows) : 1024),
-                                    dim3(256), lds, (hipStream_t)stream, (const bf16*)dy, (const bf16*)x, mean, rstd,
-                                    gamma, (bf16*)dx, (bf16*)dx_drop, dgamma, dbeta, (long)rows, H, flags,
-                                    stonk_drop_thr24(drop_p_in), 1.f / (1.f - drop_p_in), seed_in,
-                                    stonk_drop_thr24(drop_p_out), 1.f / (1.f - drop_p_out), seed_out));
+  const int grid = ln_grid(rows) < 1024 ? ln_grid(rows) : 1024;
+  // workspace (grid x 2H floats) given: partial sums + a reduce kernel instead of contended atomics
+  float* ws = (dgamma && partial_ws && ws_floats >= (int64_t)grid * 2 * H) ? partial_ws : nullptr;
+  LN_DISPATCH(H, hipLaunchKernelGGL((layernorm_bwd_kernel<CPL>), dim3(grid), dim3(256), lds, (hipStream_t)stream,
+                                    (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (bf16*)dx, (bf16*)dx_drop,
+                                    dgamma, dbeta, (long)rows, H, flags, stonk_drop_thr24(drop_p_in),
+                                    1.f / (1.f - drop_p_in), seed_in, stonk_drop_thr24(drop_p_out),
+                                    1.f / (1.f - drop_p_out), seed_out, ws));
+  if (ws)
+    hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((2 * H + 255) / 256, 32), dim3(256), 0, (hipStream_t)stream, ws, grid,
+                       H, dgamma, dbeta);
   return stonk_launch_status();
 }
 

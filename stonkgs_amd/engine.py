@@ -83,6 +83,10 @@ class Engine:
             self.ws[name] = t
         return t[:n].view(shape)
 
+    def ln_ws(self) -> torch.Tensor:
+        """Partial-sum workspace of the LayerNorm backward kernels (1024 workgroups x 2H floats)."""
+        return self.buf("ln.ws", (1024 * 2 * self.cfg.hidden_size,), F32)
+
     def check_errors(self) -> None:
         """Raise for any flag the kernels set (one tiny D2H copy; call where a sync is acceptable)."""
         e = int(self.err.item())
@@ -237,7 +241,7 @@ class Engine:
         hip.call("stonk_layernorm_bwd", dy.data_ptr(), sv["s2"].data_ptr(), sv["st2"][0].data_ptr(),
                  sv["st2"][1].data_ptr(), f(prefix + ".output.LayerNorm.weight").data_ptr(), ds2.data_ptr(), hip.ptr(df),
                  g_(prefix + ".output.LayerNorm.weight").data_ptr(), g_(prefix + ".output.LayerNorm.bias").data_ptr(),
-                 T, H, 0, 0.0, 0, p_hid, self.seed(lidx, 3), st)
+                 T, H, 0, 0.0, 0, p_hid, self.seed(lidx, 3), self.ln_ws().data_ptr(), self.ln_ws().numel(), st)
         if df is None:
             df = ds2
         # ---- FFN down: wgrad, bias grad, dgrad fused with GELU'
@@ -256,7 +260,7 @@ class Engine:
                  sv["st1"][1].data_ptr(), f(prefix + ".attention.output.LayerNorm.weight").data_ptr(), ds1.data_ptr(),
                  hip.ptr(da), g_(prefix + ".attention.output.LayerNorm.weight").data_ptr(),
                  g_(prefix + ".attention.output.LayerNorm.bias").data_ptr(), T, H, 0, 0.0, 0, p_hid, self.seed(lidx, 2),
-                 st)
+                 self.ln_ws().data_ptr(), self.ln_ws().numel(), st)
         if da is None:
             da = ds1
         # ---- attention output projection
@@ -470,7 +474,7 @@ class Engine:
         hip.call("stonk_layernorm_bwd", dt.data_ptr(), sv["gt"].data_ptr(), sv["stt"][0].data_ptr(),
                  sv["stt"][1].data_ptr(), f("cls.predictions.transform.LayerNorm.weight").data_ptr(), dgt.data_ptr(), 0,
                  g_("cls.predictions.transform.LayerNorm.weight").data_ptr(),
-                 g_("cls.predictions.transform.LayerNorm.bias").data_ptr(), T, H, 0, 0.0, 0, 0.0, 0, st)
+                 g_("cls.predictions.transform.LayerNorm.bias").data_ptr(), T, H, 0, 0.0, 0, 0.0, 0, self.ln_ws().data_ptr(), self.ln_ws().numel(), st)
         dut = self.buf("b.dut", (T, H))
         hip.call("stonk_gelu_bwd_bf16", dgt.data_ptr(), sv["ut"].data_ptr(), dut.data_ptr(), T * H, st)
         self.wgrad(dut, sv["seq_out"], g_("cls.predictions.transform.dense.weight"),
@@ -536,7 +540,7 @@ class Engine:
         hip.call("stonk_layernorm_bwd", dy.data_ptr(), sv["sum0"].data_ptr(), sv["st0"][0].data_ptr(),
                  sv["st0"][1].data_ptr(), f("bert.embeddings.LayerNorm.weight").data_ptr(), dsum.data_ptr(), 0,
                  g_("bert.embeddings.LayerNorm.weight").data_ptr(), g_("bert.embeddings.LayerNorm.bias").data_ptr(), T, H,
-                 hip.LN_DROPOUT if p_hid > 0 else 0, p_hid, self.seed(200, 0), 0.0, 0, st)
+                 hip.LN_DROPOUT if p_hid > 0 else 0, p_hid, self.seed(200, 0), 0.0, 0, self.ln_ws().data_ptr(), self.ln_ws().numel(), st)
         hip.call("stonk_embed_grad", dsum.data_ptr(), hip.ptr(sv["token_type_ids"]),
                  g_("bert.embeddings.position_embeddings.weight").data_ptr(),
                  g_("bert.embeddings.token_type_embeddings.weight").data_ptr(), B, S, H, cfg.type_vocab_size, st)

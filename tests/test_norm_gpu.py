@@ -6,6 +6,27 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+class _LazyWs:
+    """Partial-sum workspace for stonk_layernorm_bwd (1024 workgroups x 2H floats), created on first use."""
+
+    def __init__(self):
+        self.t = None
+
+    def get(self):
+        if self.t is None:
+            self.t = torch.empty(1024 * 2 * 1024, device="cuda")
+        return self.t
+
+    def data_ptr(self):
+        return self.get().data_ptr()
+
+    def numel(self):
+        return self.get().numel()
+
+
+LN_WS = _LazyWs()
+
+
 def _rand(shape, scale=1.0, seed=0, dtype=torch.bfloat16):
     g = torch.Generator(device="cuda").manual_seed(seed)
     return (torch.randn(shape, device="cuda", generator=g) * scale).to(dtype)
@@ -32,7 +53,7 @@ def test_layernorm_fwd_bwd(hip, rows, H):
     dgamma = torch.zeros(H, device="cuda")
     dbeta = torch.zeros(H, device="cuda")
     hip.call("stonk_layernorm_bwd", hip.ptr(dy), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(dx),
-             0, hip.ptr(dgamma), hip.ptr(dbeta), rows, H, 0, 0.0, 0, 0.0, 0, hip.stream_ptr())
+             0, hip.ptr(dgamma), hip.ptr(dbeta), rows, H, 0, 0.0, 0, 0.0, 0, hip.ptr(LN_WS), LN_WS.numel(), hip.stream_ptr())
     torch.testing.assert_close(dx.float(), xf.grad, rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(dgamma, gf.grad, rtol=1e-3, atol=1e-2)
     torch.testing.assert_close(dbeta, bf.grad, rtol=1e-3, atol=1e-2)
@@ -61,7 +82,7 @@ def test_layernorm_dropout_consistency(hip):
     dg = torch.zeros(H, device="cuda")
     db = torch.zeros(H, device="cuda")
     hip.call("stonk_layernorm_bwd", hip.ptr(dy), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(dx),
-             hip.ptr(dxd), hip.ptr(dg), hip.ptr(db), rows, H, hip.LN_DROPOUT, 0.1, 77, 0.1, 78, hip.stream_ptr())
+             hip.ptr(dxd), hip.ptr(dg), hip.ptr(db), rows, H, hip.LN_DROPOUT, 0.1, 77, 0.1, 78, hip.ptr(LN_WS), LN_WS.numel(), hip.stream_ptr())
     dy_m = torch.where(kept, dy.float() / 0.9, torch.zeros((), device="cuda"))
     xf = x.float().requires_grad_(True)
     F.layer_norm(xf, (H,), gamma, beta, 1e-12).backward(dy_m)

@@ -67,8 +67,9 @@ def bench_ln():
     dx = torch.empty_like(x)
     dg = torch.zeros(H, device="cuda")
     db = torch.zeros(H, device="cuda")
+    LN_WS = torch.empty(1024 * 2 * H, device="cuda")
     t = timeit(lambda: hip.call("stonk_layernorm_bwd", hip.ptr(y), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(g),
-                                hip.ptr(dx), 0, hip.ptr(dg), hip.ptr(db), rows, H, 0, 0.0, 0, 0.0, 0, hip.stream_ptr()))
+                                hip.ptr(dx), 0, hip.ptr(dg), hip.ptr(db), rows, H, 0, 0.0, 0, 0.0, 0, hip.ptr(LN_WS), LN_WS.numel(), hip.stream_ptr()))
     print(f"layernorm_bwd {rows}x{H}: {t*1e6:.1f} us  {rows*H*6/t/1e9:.0f} GB/s", flush=True)
 
 

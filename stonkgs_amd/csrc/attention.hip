@@ -22,9 +22,14 @@ constexpr int HD = 64;        // head dim
 constexpr int TK = 64;        // rows per LDS tile
 constexpr int ROWB = 128;     // bytes per tile row
 constexpr int TILEB = TK * ROWB;
+constexpr int STAGEB = 2 * TILEB + 2 * TK * 4;   // two [64][64] bf16 tiles + two rows of 64 floats
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
-constexpr float NEG_BIG = -1.0e30f;
+// Additive key-padding bias in RAW score units, entered as the MFMA accumulator's initial value. A power of two: the
+// products are absorbed (every masked score is exactly NEG_MASK, as the reference's finfo.min absorbs them) and
+// NEG_MASK * scale is exact, so exp2(fma(s, scale, -max)) is exactly 1 for a row whose keys are all masked.
+constexpr float NEG_MASK = -0x1p100f;
+constexpr float NEG_INIT = -0x1p120f;
 
 struct AttnArgs {
   const bf16* q;
@@ -32,22 +37,22 @@ struct AttnArgs {
   const bf16* v;
   long ld;            // row stride (elements) of q/k/v
   const long* mask;   // [B,S] or null
-  bf16* out;          // fwd: context [T, ldo]
+  bf16* out;          // fwd: context [T, ldo]; bwd: the forward's context (read)
   long ldo;
   float* lse;         // [B, NH, S] natural-log LSE of the scaled+masked scores
   // backward only
   const bf16* dout;   // [T, lddo]
   long lddo;
-  const float* delta; // [B, NH, S]
+  float* delta;       // [B, NH, S] rowsum(dO * O): written by the dQ kernel, read by the dK/dV kernel
   bf16* dq;
   bf16* dk;
   bf16* dv;
   long ldd;           // row stride of dq/dk/dv
   int B, NH, S;
   float scale;
-  uint32_t drop_thr24;
+  uint32_t drop_thr32;
   float drop_scale;
-  uint32_t seed;
+  uint32_t seed;      // mixed (stonk_seed_mix)
 };
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
@@ -58,6 +63,43 @@ __device__ __forceinline__ int tile_off(int row, int col) {
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// Maximum of a 32x32 MFMA accumulator tile's 16 registers (and a running value) in eight v_max3_f32. fmaxf on MFMA
+// results would make the compiler canonicalise every input first (one more VALU op per element), hence the asm - but the
+// hazard recogniser does not see asm operands, so the statement carries its own wait for the MFMA that produced its
+// inputs (an XDL write needs up to 19 wait states before a VALU read of the same registers).
+__device__ __forceinline__ float max16_mfma(const f32x16& a) {
+  float d;
+  asm("s_nop 15\n\ts_nop 3\n\t"
+      "v_max3_f32 %0, %1, %2, %3\n\t"
+      "v_max3_f32 %0, %0, %4, %5\n\t"
+      "v_max3_f32 %0, %0, %6, %7\n\t"
+      "v_max3_f32 %0, %0, %8, %9\n\t"
+      "v_max3_f32 %0, %0, %10, %11\n\t"
+      "v_max3_f32 %0, %0, %12, %13\n\t"
+      "v_max3_f32 %0, %0, %14, %15\n\t"
+      "v_max3_f32 %0, %0, %16, %16"
+      : "=&v"(d)
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
+        "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]));
+  return d;
+}
+// same, folded into a running maximum (the compiler orders the two tiles' MFMAs freely, so this one waits as well)
+__device__ __forceinline__ float max16_chain(float t, const f32x16& a) {
+  float d;
+  asm("s_nop 15\n\ts_nop 3\n\t"
+      "v_max3_f32 %0, %17, %1, %2\n\t"
+      "v_max3_f32 %0, %0, %3, %4\n\t"
+      "v_max3_f32 %0, %0, %5, %6\n\t"
+      "v_max3_f32 %0, %0, %7, %8\n\t"
+      "v_max3_f32 %0, %0, %9, %10\n\t"
+      "v_max3_f32 %0, %0, %11, %12\n\t"
+      "v_max3_f32 %0, %0, %13, %14\n\t"
+      "v_max3_f32 %0, %0, %15, %16"
+      : "=&v"(d)
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
+        "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]), "v"(t));
+  return d;
 }
 
 // A/B fragment of a 32x32x16 MFMA read by rows: lane (r, hh) gets tile[row0 + r][16*st + 8*hh .. +7]
@@ -96,17 +138,18 @@ __device__ __forceinline__ void stage_store(const Stage2& s, char* tile, int tid
   }
 }
 
-__device__ __forceinline__ float keep_fac(uint32_t idx, const AttnArgs& p) {
-  return stonk_keep(idx, p.seed, p.drop_thr24) ? p.drop_scale : 0.f;
-}
+// Every kernel below runs the same pipeline: tile t+1 is fetched into registers while tile t is computed from LDS
+// stage t&1, written to the other stage when the compute is done, ONE barrier per tile.
+//
+// Dropout: element (query row, key) is kept iff stonk_keep_key(rowkey(flat (b,h,q)), colkey(key)); both keys are
+// linear, so the kernel with the query on the lane adds a compile-time constant to the tile's column key per element
+// and the kernel with the key on the lane does the same with the row key. The 1/(1-p) factor never touches an
+// element: it is folded into the output normalisation (forward, dV) or into delta and the final scale (dQ, dK).
 
 // ------------------------------------------------------------------ forward
 template <bool HAS_MASK, bool DROPOUT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * TILEB + TK * 4];
-  char* Ks = lds;
-  char* Vs = lds + TILEB;
-  float* Mb = (float*)(lds + 2 * TILEB);
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGEB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -124,69 +167,76 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   f32x16 o[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) o[0][i] = o[1][i] = 0.f;
-  float m = NEG_BIG, l = 0.f;
+  float m = NEG_INIT, l = 0.f;   // m in scaled log2 units
 
   const bf16* kbase = p.k + tok0 * p.ld + h * HD;
   const bf16* vbase = p.v + tok0 * p.ld + h * HD;
   const int ntiles = S / TK;
+  const uint32_t rk = stonk_rowkey((uint32_t)((b * p.NH + h) * S + q0 + r), p.seed);
+  const uint32_t ck_lane = stonk_colkey((uint32_t)(4 * hh));
+
   Stage2 sk, sv;
-  stage_load(sk, kbase, p.ld, tid);
-  stage_load(sv, vbase, p.ld, tid);
-  const uint32_t drop_row = (uint32_t)(((long)(b * p.NH + h) * S + q0 + r) * S);
+  long mreg = 1;
+  auto load_tile = [&](int kt) {
+    stage_load(sk, kbase + (long)kt * TK * p.ld, p.ld, tid);
+    stage_load(sv, vbase + (long)kt * TK * p.ld, p.ld, tid);
+    if (HAS_MASK && tid < TK) mreg = p.mask[tok0 + kt * TK + tid];
+  };
+  auto store_tile = [&](int buf) {
+    char* base = lds + buf * STAGEB;
+    stage_store(sk, base, tid);
+    stage_store(sv, base + TILEB, tid);
+    if (HAS_MASK && tid < TK) ((float*)(base + 2 * TILEB))[tid] = mreg != 0 ? 0.f : NEG_MASK;
+  };
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
 
   for (int kt = 0; kt < ntiles; ++kt) {
-    stage_store(sk, Ks, tid);
-    stage_store(sv, Vs, tid);
-    if (HAS_MASK && tid < TK) Mb[tid] = p.mask[tok0 + kt * TK + tid] != 0 ? 0.f : NEG_BIG;
-    __syncthreads();
-    if (kt + 1 < ntiles) {
-      stage_load(sk, kbase + (long)(kt + 1) * TK * p.ld, p.ld, tid);
-      stage_load(sv, vbase + (long)(kt + 1) * TK * p.ld, p.ld, tid);
-    }
-    // S^T = K . Q^T for the two 32-key halves of the tile
+    const char* Ks = lds + (kt & 1) * STAGEB;
+    const char* Vs = Ks + TILEB;
+    const float* Mb = (const float*)(Ks + 2 * TILEB);
+    if (kt + 1 < ntiles) load_tile(kt + 1);
+    // S^T = K . Q^T (+ key bias through the accumulator) for the two 32-key halves of the tile, raw units
     f32x16 s[2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s[sub][i] = 0.f;
-#pragma unroll
-      for (int st = 0; st < 4; ++st) s[sub] = mfma32(row_frag(Ks, sub * 32, st, r, hh), qf[st], s[sub]);
-    }
-    float tmax = NEG_BIG;
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 mb = {0.f, 0.f, 0.f, 0.f};
         if (HAS_MASK) mb = *(const f32x4*)(Mb + sub * 32 + 8 * g + 4 * hh);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float t = s[sub][4 * g + j] * sc2 + mb[j];
-          s[sub][4 * g + j] = t;
-          tmax = fmaxf(tmax, t);
-        }
+        for (int j = 0; j < 4; ++j) s[sub][4 * g + j] = mb[j];
       }
+#pragma unroll
+      for (int st = 0; st < 4; ++st) s[sub] = mfma32(row_frag(Ks, sub * 32, st, r, hh), qf[st], s[sub]);
+    }
+    float tmax = max16_chain(max16_mfma(s[1]), s[0]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m, tmax);
+    const float m_new = fmaxf(m, tmax * sc2);
     const float alpha = __builtin_amdgcn_exp2f(m - m_new);
     m = m_new;
+    const float negm = -m_new;
     float rs = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float e = __builtin_amdgcn_exp2f(s[sub][i] - m);
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][i], sc2, negm));
         s[sub][i] = e;
         rs += e;
       }
     rs += __shfl_xor(rs, 32, 64);
     l = l * alpha + rs;
+    if (!__all(alpha == 1.f)) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      o[0][i] *= alpha;
-      o[1][i] *= alpha;
+      for (int i = 0; i < 16; ++i) {
+        o[0][i] *= alpha;
+        o[1][i] *= alpha;
+      }
     }
     // O^T += V^T . P^T
+    const uint32_t ckt = ck_lane + (uint32_t)(kt * TK) * STONK_G_COL;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -196,17 +246,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         for (int j = 0; j < 8; ++j) {
           float e = s[sub][8 * ks + j];
           if (DROPOUT) {
-            const int key = kt * TK + sub * 32 + 16 * ks + 8 * (j >> 2) + 4 * hh + (j & 3);
-            e *= keep_fac(drop_row + key, p);
+            const uint32_t cj = (uint32_t)(sub * 32 + 16 * ks + 8 * (j >> 2) + (j & 3)) * STONK_G_COL;
+            e = stonk_keep_key(rk, ckt + cj, p.drop_thr32) ? e : 0.f;
           }
           pf[j] = (bf16)e;
         }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(tr_frag(Vs, sub * 32 + 16 * ks, dt * 32, lane), pf, o[dt]);
       }
+    if (kt + 1 < ntiles) store_tile((kt + 1) & 1);
     __syncthreads();
   }
-  const float inv = 1.f / l;
+  const float inv = (DROPOUT ? p.drop_scale : 1.f) / l;
   bf16* orow = p.out + (tok0 + q0 + r) * p.ldo + h * HD;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -219,42 +270,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   if (hh == 0 && p.lse) p.lse[(long)(b * p.NH + h) * S + q0 + r] = (m + __builtin_amdgcn_logf(l)) * LN2;
 }
 
-// ------------------------------------------------------------------ delta = rowsum(dO * O) per (b, h, q)
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, long ldo,
-                                                         const bf16* __restrict__ dout, long lddo,
-                                                         float* __restrict__ delta, int B, int NH, int S) {
-  // one 8-lane group per (token, head): 8 x 16-byte chunks = 64 columns
-  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
-  const int sub = threadIdx.x & 7;
-  const long total = (long)B * S * NH;
-  float acc = 0.f;
-  if (gid < total) {
-    const long tok = gid / NH;
-    const int h = (int)(gid - tok * NH);
-    const bf16x8 a = *(const bf16x8*)(o + tok * ldo + h * HD + sub * 8);
-    const bf16x8 d = *(const bf16x8*)(dout + tok * lddo + h * HD + sub * 8);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)d[j];
-  }
-  acc += __shfl_xor(acc, 1, 64);
-  acc += __shfl_xor(acc, 2, 64);
-  acc += __shfl_xor(acc, 4, 64);
-  if (gid < total && sub == 0) {
-    const long tok = gid / NH;
-    const int h = (int)(gid - tok * NH);
-    const long b = tok / S;
-    const int s = (int)(tok - b * S);
-    delta[((long)b * NH + h) * S + s] = acc;
-  }
-}
-
 // ------------------------------------------------------------------ backward: dQ (query on the lane)
+// Also produces delta = rowsum(dO * O) for its query rows (the dK/dV kernel, launched after it, reads it).
 template <bool HAS_MASK, bool DROPOUT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * TILEB + TK * 4];
-  char* Ks = lds;
-  char* Vs = lds + TILEB;
-  float* Mb = (float*)(lds + 2 * TILEB);
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGEB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -264,18 +284,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
   const float sc2 = p.scale * LOG2E;
 
   bf16x8 qf[4], dof[4];
+  float dlt = 0.f;
   {
     const bf16* qrow = p.q + (tok0 + q0 + r) * p.ld + h * HD;
     const bf16* drow = p.dout + (tok0 + q0 + r) * p.lddo + h * HD;
+    const bf16* orow = p.out + (tok0 + q0 + r) * p.ldo + h * HD;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       qf[st] = *(const bf16x8*)(qrow + 16 * st + 8 * hh);
       dof[st] = *(const bf16x8*)(drow + 16 * st + 8 * hh);
+      const bf16x8 of = *(const bf16x8*)(orow + 16 * st + 8 * hh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dlt += (float)of[j] * (float)dof[st][j];
     }
   }
+  dlt += __shfl_xor(dlt, 32, 64);
   const long stat = (long)(b * p.NH + h) * S + q0 + r;
-  const float lse2 = p.lse[stat] * LOG2E;
-  const float dlt = p.delta[stat];
+  if (hh == 0) p.delta[stat] = dlt;
+  const float nlse2 = -p.lse[stat] * LOG2E;
+  // dS = P * (drop(dP) - delta) with drop(dP) = keep ? dP / (1-p) : 0  ==  (1/(1-p)) * P * ((keep ? dP : 0) - (1-p) delta)
+  const float dlt_s = DROPOUT ? dlt / p.drop_scale : dlt;
   f32x16 dq[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) dq[0][i] = dq[1][i] = 0.f;
@@ -283,42 +311,59 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
   const bf16* kbase = p.k + tok0 * p.ld + h * HD;
   const bf16* vbase = p.v + tok0 * p.ld + h * HD;
   const int ntiles = S / TK;
+  const uint32_t rk = stonk_rowkey((uint32_t)stat, p.seed);
+  const uint32_t ck_lane = stonk_colkey((uint32_t)(4 * hh));
+
   Stage2 sk, sv;
-  stage_load(sk, kbase, p.ld, tid);
-  stage_load(sv, vbase, p.ld, tid);
-  const uint32_t drop_row = (uint32_t)(((long)(b * p.NH + h) * S + q0 + r) * S);
+  long mreg = 1;
+  auto load_tile = [&](int kt) {
+    stage_load(sk, kbase + (long)kt * TK * p.ld, p.ld, tid);
+    stage_load(sv, vbase + (long)kt * TK * p.ld, p.ld, tid);
+    if (HAS_MASK && tid < TK) mreg = p.mask[tok0 + kt * TK + tid];
+  };
+  auto store_tile = [&](int buf) {
+    char* base = lds + buf * STAGEB;
+    stage_store(sk, base, tid);
+    stage_store(sv, base + TILEB, tid);
+    if (HAS_MASK && tid < TK) ((float*)(base + 2 * TILEB))[tid] = mreg != 0 ? 0.f : NEG_MASK;
+  };
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
 
   for (int kt = 0; kt < ntiles; ++kt) {
-    stage_store(sk, Ks, tid);
-    stage_store(sv, Vs, tid);
-    if (HAS_MASK && tid < TK) Mb[tid] = p.mask[tok0 + kt * TK + tid] != 0 ? 0.f : NEG_BIG;
-    __syncthreads();
-    if (kt + 1 < ntiles) {
-      stage_load(sk, kbase + (long)(kt + 1) * TK * p.ld, p.ld, tid);
-      stage_load(sv, vbase + (long)(kt + 1) * TK * p.ld, p.ld, tid);
-    }
+    const char* Ks = lds + (kt & 1) * STAGEB;
+    const char* Vs = Ks + TILEB;
+    const float* Mb = (const float*)(Ks + 2 * TILEB);
+    if (kt + 1 < ntiles) load_tile(kt + 1);
+    const uint32_t ckt = ck_lane + (uint32_t)(kt * TK) * STONK_G_COL;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        s = mfma32(row_frag(Ks, sub * 32, st, r, hh), qf[st], s);      // S^T[k][q]
-        dp = mfma32(row_frag(Vs, sub * 32, st, r, hh), dof[st], dp);   // dP^T[k][q] = sum_d V[k][d] dO[q][d]
-      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 mb = {0.f, 0.f, 0.f, 0.f};
         if (HAS_MASK) mb = *(const f32x4*)(Mb + sub * 32 + 8 * g + 4 * hh);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int i = 4 * g + j;
-          const float pr = __builtin_amdgcn_exp2f(s[i] * sc2 + mb[j] - lse2);
-          float dpv = dp[i];
-          if (DROPOUT) dpv *= keep_fac(drop_row + kt * TK + sub * 32 + 8 * g + 4 * hh + j, p);
-          s[i] = pr * (dpv - dlt);  // dS^T
+          s[4 * g + j] = mb[j];
+          dp[4 * g + j] = 0.f;
         }
+      }
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        s = mfma32(row_frag(Ks, sub * 32, st, r, hh), qf[st], s);      // S^T[k][q] (+ key bias)
+        dp = mfma32(row_frag(Vs, sub * 32, st, r, hh), dof[st], dp);   // dP^T[k][q] = sum_d V[k][d] dO[q][d]
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sc2, nlse2));
+        float dpv = dp[i];
+        if (DROPOUT) {
+          const uint32_t cj = (uint32_t)(sub * 32 + 8 * (i >> 2) + (i & 3)) * STONK_G_COL;
+          dpv = stonk_keep_key(rk, ckt + cj, p.drop_thr32) ? dpv : 0.f;
+        }
+        s[i] = pr * (dpv - dlt_s);  // dS^T (up to the folded 1/(1-p))
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -329,27 +374,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
         for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tr_frag(Ks, sub * 32 + 16 * ks, dt * 32, lane), dsf, dq[dt]);
       }
     }
+    if (kt + 1 < ntiles) store_tile((kt + 1) & 1);
     __syncthreads();
   }
+  const float fs = DROPOUT ? p.scale * p.drop_scale : p.scale;
   bf16* orow = p.dq + (tok0 + q0 + r) * p.ldd + h * HD;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      bf16x4 v = {(bf16)(dq[dt][4 * g] * p.scale), (bf16)(dq[dt][4 * g + 1] * p.scale),
-                  (bf16)(dq[dt][4 * g + 2] * p.scale), (bf16)(dq[dt][4 * g + 3] * p.scale)};
+      bf16x4 v = {(bf16)(dq[dt][4 * g] * fs), (bf16)(dq[dt][4 * g + 1] * fs), (bf16)(dq[dt][4 * g + 2] * fs),
+                  (bf16)(dq[dt][4 * g + 3] * fs)};
       *(bf16x4*)(orow + dt * 32 + 8 * g + 4 * hh) = v;
     }
 }
 
 // ------------------------------------------------------------------ backward: dK, dV (key on the lane)
 template <bool HAS_MASK, bool DROPOUT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * TILEB + 2 * TK * 4];
-  char* Qs = lds;
-  char* Ds = lds + TILEB;
-  float* Ls = (float*)(lds + 2 * TILEB);  // lse * log2(e) per query row of the tile
-  float* Dl = Ls + TK;                    // delta per query row
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGEB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -369,7 +412,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     }
   }
   float mb = 0.f;
-  if (HAS_MASK) mb = p.mask[tok0 + k0 + r] != 0 ? 0.f : NEG_BIG;
+  if (HAS_MASK) mb = p.mask[tok0 + k0 + r] != 0 ? 0.f : NEG_MASK;
   f32x16 dk[2], dv[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;
@@ -378,45 +421,65 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
   const bf16* dbase = p.dout + tok0 * p.lddo + h * HD;
   const long statbase = (long)(b * p.NH + h) * S;
   const int ntiles = S / TK;
+  const uint32_t rk_lane = stonk_rowkey((uint32_t)(statbase + 4 * hh), p.seed);
+  const uint32_t ck = stonk_colkey((uint32_t)(k0 + r));
+  const float inv_ds = DROPOUT ? 1.f / p.drop_scale : 1.f;
+
   Stage2 sq, sd;
-  stage_load(sq, qbase, p.ld, tid);
-  stage_load(sd, dbase, p.lddo, tid);
+  float sreg = 0.f;
+  auto load_tile = [&](int qt) {
+    stage_load(sq, qbase + (long)qt * TK * p.ld, p.ld, tid);
+    stage_load(sd, dbase + (long)qt * TK * p.lddo, p.lddo, tid);
+    if (tid < TK) sreg = -p.lse[statbase + qt * TK + tid] * LOG2E;            // -lse in log2 units
+    else if (tid < 2 * TK) sreg = p.delta[statbase + qt * TK + tid - TK] * inv_ds;  // (1-p) * delta
+  };
+  auto store_tile = [&](int buf) {
+    char* base = lds + buf * STAGEB;
+    stage_store(sq, base, tid);
+    stage_store(sd, base + TILEB, tid);
+    if (tid < 2 * TK) ((float*)(base + 2 * TILEB))[tid] = sreg;
+  };
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
 
   for (int qt = 0; qt < ntiles; ++qt) {
-    stage_store(sq, Qs, tid);
-    stage_store(sd, Ds, tid);
-    if (tid < TK) Ls[tid] = p.lse[statbase + qt * TK + tid] * LOG2E;
-    else if (tid < 2 * TK) Dl[tid - TK] = p.delta[statbase + qt * TK + tid - TK];
-    __syncthreads();
-    if (qt + 1 < ntiles) {
-      stage_load(sq, qbase + (long)(qt + 1) * TK * p.ld, p.ld, tid);
-      stage_load(sd, dbase + (long)(qt + 1) * TK * p.lddo, p.lddo, tid);
-    }
+    const char* Qs = lds + (qt & 1) * STAGEB;
+    const char* Ds = Qs + TILEB;
+    const float* Ls = (const float*)(Qs + 2 * TILEB);
+    const float* Dl = Ls + TK;
+    if (qt + 1 < ntiles) load_tile(qt + 1);
+    const uint32_t rkt = rk_lane + (uint32_t)(qt * TK) * STONK_G_ROW;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+      for (int i = 0; i < 16; ++i) {
+        s[i] = mb;
+        dp[i] = 0.f;
+      }
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
-        s = mfma32(row_frag(Qs, sub * 32, st, r, hh), kf[st], s);    // S[q][k]
+        s = mfma32(row_frag(Qs, sub * 32, st, r, hh), kf[st], s);    // S[q][k] (+ key bias)
         dp = mfma32(row_frag(Ds, sub * 32, st, r, hh), vf[st], dp);  // dP[q][k] = sum_d dO[q][d] V[k][d]
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 ls = *(const f32x4*)(Ls + sub * 32 + 8 * g + 4 * hh);
+        const f32x4 nls = *(const f32x4*)(Ls + sub * 32 + 8 * g + 4 * hh);
         const f32x4 dl = *(const f32x4*)(Dl + sub * 32 + 8 * g + 4 * hh);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int i = 4 * g + j;
-          const float pr = __builtin_amdgcn_exp2f(s[i] * sc2 + mb - ls[j]);
-          float fac = 1.f;
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sc2, nls[j]));
+          float pd = pr, dpv = dp[i];
           if (DROPOUT) {
-            const int qrow = qt * TK + sub * 32 + 8 * g + 4 * hh + j;
-            fac = keep_fac((uint32_t)((statbase + qrow) * S + k0 + r), p);
+            const uint32_t rj = (uint32_t)(sub * 32 + 8 * g + j) * STONK_G_ROW;
+            const bool keep = stonk_keep_key(rkt + rj, ck, p.drop_thr32);
+            pd = keep ? pr : 0.f;
+            dpv = keep ? dpv : 0.f;
           }
-          s[i] = pr * fac;                        // dropped P (feeds dV)
-          dp[i] = pr * (dp[i] * fac - dl[j]);     // dS (feeds dK)
+          s[i] = pd;                       // dropped P (feeds dV), up to the folded 1/(1-p)
+          dp[i] = pr * (dpv - dl[j]);      // dS (feeds dK), up to the folded 1/(1-p)
         }
       }
 #pragma unroll
@@ -434,17 +497,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         }
       }
     }
+    if (qt + 1 < ntiles) store_tile((qt + 1) & 1);
     __syncthreads();
   }
+  const float fk = DROPOUT ? p.scale * p.drop_scale : p.scale;
+  const float fv = DROPOUT ? p.drop_scale : 1.f;
   bf16* krow = p.dk + (tok0 + k0 + r) * p.ldd + h * HD;
   bf16* vrow = p.dv + (tok0 + k0 + r) * p.ldd + h * HD;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      bf16x4 a = {(bf16)(dk[dt][4 * g] * p.scale), (bf16)(dk[dt][4 * g + 1] * p.scale),
-                  (bf16)(dk[dt][4 * g + 2] * p.scale), (bf16)(dk[dt][4 * g + 3] * p.scale)};
-      bf16x4 c = {(bf16)dv[dt][4 * g], (bf16)dv[dt][4 * g + 1], (bf16)dv[dt][4 * g + 2], (bf16)dv[dt][4 * g + 3]};
+      bf16x4 a = {(bf16)(dk[dt][4 * g] * fk), (bf16)(dk[dt][4 * g + 1] * fk), (bf16)(dk[dt][4 * g + 2] * fk),
+                  (bf16)(dk[dt][4 * g + 3] * fk)};
+      bf16x4 c = {(bf16)(dv[dt][4 * g] * fv), (bf16)(dv[dt][4 * g + 1] * fv), (bf16)(dv[dt][4 * g + 2] * fv),
+                  (bf16)(dv[dt][4 * g + 3] * fv)};
       *(bf16x4*)(krow + dt * 32 + 8 * g + 4 * hh) = a;
       *(bf16x4*)(vrow + dt * 32 + 8 * g + 4 * hh) = c;
     }
@@ -456,7 +523,7 @@ int check_common(const void* q, const void* k, const void* v, int64_t ld, int B,
   STONK_CHECK_ARG(B >= 0 && NH > 0 && S > 0 && S % 128 == 0, STONK_ESHAPE);
   STONK_CHECK_ARG(ld % 8 == 0, STONK_EALIGN);
   STONK_CHECK_ARG((uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0, STONK_EALIGN);
-  STONK_CHECK_ARG((long)B * NH * S * S < (1L << 32), STONK_ESHAPE);  // 32-bit dropout counter
+  STONK_CHECK_ARG((long)B * NH * S < (1L << 32), STONK_ESHAPE);  // 32-bit dropout row counter
   return STONK_OK;
 }
 
@@ -474,7 +541,7 @@ extern "C" int stonk_attention_fwd(const void* q, const void* k, const void* v, 
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
   a.mask = (const long*)attention_mask; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse;
   a.B = B; a.NH = NH; a.S = S; a.scale = scale;
-  a.drop_thr24 = stonk_drop_thr24(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed;
+  a.drop_thr32 = stonk_drop_thr32(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = stonk_seed_mix(seed);
   const dim3 grid(S / 128, NH, B), block(256);
   hipStream_t st = (hipStream_t)stream;
   const bool hm = attention_mask != nullptr, dr = drop_p > 0.f;
@@ -498,15 +565,12 @@ extern "C" int stonk_attention_bwd(const void* q, const void* k, const void* v, 
   if (B == 0) return STONK_OK;
   AttnArgs a = {};
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
-  a.mask = (const long*)attention_mask; a.lse = (float*)lse;
+  a.mask = (const long*)attention_mask; a.lse = (float*)lse; a.out = (bf16*)out; a.ldo = ldo;
   a.dout = (const bf16*)dout; a.lddo = lddo; a.delta = delta_ws;
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ldd = ldd;
   a.B = B; a.NH = NH; a.S = S; a.scale = scale;
-  a.drop_thr24 = stonk_drop_thr24(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = seed;
+  a.drop_thr32 = stonk_drop_thr32(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = stonk_seed_mix(seed);
   hipStream_t st = (hipStream_t)stream;
-  const long groups = (long)B * S * NH;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, st,
-                     (const bf16*)out, (long)ldo, (const bf16*)dout, (long)lddo, delta_ws, B, NH, S);
   const dim3 grid(S / 128, NH, B), block(256);
   const bool hm = attention_mask != nullptr, dr = drop_p > 0.f;
 #define LAUNCH_BWD(HM, DR)                                                                  \

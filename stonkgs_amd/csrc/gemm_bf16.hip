@@ -231,9 +231,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
             for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)sa[i][j][r]);
           }
           if (EPI & STONK_EPI_DROPOUT) {
-            const uint32_t e = (uint32_t)((long)m * p.N + n);
+            const uint32_t rk = stonk_rowkey((uint32_t)m, p.seed), ck = stonk_colkey((uint32_t)n);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = stonk_keep(e + r, p.seed, p.drop_thr24) ? v[r] * p.drop_scale : 0.f;
+            for (int r = 0; r < 4; ++r)
+              v[r] = stonk_keep_key(rk, ck + (uint32_t)r * STONK_G_COL, p.drop_thr32) ? v[r] * p.drop_scale : 0.f;
           }
           if (EPI & STONK_EPI_RESID) {
 #pragma unroll
@@ -306,9 +307,9 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   a.bias = bias; a.resid = (const bf16*)resid; a.aux = (bf16*)aux; a.m_dev = m_dev; a.k_dev = k_dev;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.ldaux = ldaux;
   a.M = M; a.N = N; a.K = K; a.flags = flags; a.alpha = alpha; a.split_k = split_k;
-  a.drop_thr24 = stonk_drop_thr24(drop_p);
+  a.drop_thr32 = stonk_drop_thr32(drop_p);
   a.drop_scale = 1.0f / (1.0f - drop_p);
-  a.seed = seed;
+  a.seed = stonk_seed_mix(seed);
 
   hipStream_t st = (hipStream_t)stream;
   // large launches go to the persistent 256x256 kernel (gemm256.hip); small ones keep the 128x128 tiles

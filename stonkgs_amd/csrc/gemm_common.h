@@ -20,9 +20,9 @@ struct GemmArgs {
   int flags;
   float alpha;
   int split_k;
-  uint32_t drop_thr24;
+  uint32_t drop_thr32;
   float drop_scale;
-  uint32_t seed;
+  uint32_t seed;      // already mixed (stonk_seed_mix)
 };
 
 // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of tiles so
@@ -51,9 +51,10 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& p, int flags
     for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)u[r]);
   }
   if (flags & STONK_EPI_DROPOUT) {
-    const uint32_t e = (uint32_t)((long)m * p.N + n);
+    const uint32_t rk = stonk_rowkey((uint32_t)m, p.seed), ck = stonk_colkey((uint32_t)n);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = stonk_keep(e + r, p.seed, p.drop_thr24) ? v[r] * p.drop_scale : 0.f;
+    for (int r = 0; r < 4; ++r)
+      v[r] = stonk_keep_key(rk, ck + (uint32_t)r * STONK_G_COL, p.drop_thr32) ? v[r] * p.drop_scale : 0.f;
   }
   if (flags & STONK_EPI_RESID) {
     const bf16x4 rr = *(const bf16x4*)(p.resid + (long)m * p.ldr + n);
@@ -90,9 +91,10 @@ __device__ __forceinline__ void epilogue8(float (&v)[8], const GemmArgs& p, int 
     for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad((float)u[r]);
   }
   if (flags & STONK_EPI_DROPOUT) {
-    const uint32_t e = (uint32_t)((long)m * p.N + n);
+    const uint32_t rk = stonk_rowkey((uint32_t)m, p.seed), ck = stonk_colkey((uint32_t)n);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = stonk_keep(e + r, p.seed, p.drop_thr24) ? v[r] * p.drop_scale : 0.f;
+    for (int r = 0; r < 8; ++r)
+      v[r] = stonk_keep_key(rk, ck + (uint32_t)r * STONK_G_COL, p.drop_thr32) ? v[r] * p.drop_scale : 0.f;
   }
   if (flags & STONK_EPI_RESID) {
     const bf16x8 rr = *(const bf16x8*)(p.resid + (long)m * p.ldr + n);
@@ -145,9 +147,10 @@ __device__ __forceinline__ void epilogue8_pre(float (&v)[8], const GemmArgs& p, 
     for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad((float)s.aux[r]);
   }
   if (flags & STONK_EPI_DROPOUT) {
-    const uint32_t e = (uint32_t)((long)m * p.N + n);
+    const uint32_t rk = stonk_rowkey((uint32_t)m, p.seed), ck = stonk_colkey((uint32_t)n);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = stonk_keep(e + r, p.seed, p.drop_thr24) ? v[r] * p.drop_scale : 0.f;
+    for (int r = 0; r < 8; ++r)
+      v[r] = stonk_keep_key(rk, ck + (uint32_t)r * STONK_G_COL, p.drop_thr32) ? v[r] * p.drop_scale : 0.f;
   }
   if (flags & STONK_EPI_RESID) {
 #pragma unroll

@@ -110,7 +110,7 @@ __device__ __forceinline__ void row_stats(const RowRegs<CPL>& r, int nch, int la
 template <int CPL>
 __device__ __forceinline__ void normalize_store(RowRegs<CPL>& r, int nch, int lane, float mean, float rstd,
                                                 const float* gamma, const float* beta, bf16* yrow, long row_idx, int H,
-                                                bool drop, uint32_t thr24, float dscale, uint32_t seed) {
+                                                bool drop, uint32_t thr32, float dscale, uint32_t seed) {
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
     const int c = lane + 64 * i;
@@ -123,7 +123,7 @@ __device__ __forceinline__ void normalize_store(RowRegs<CPL>& r, int nch, int la
         const float g = j < 4 ? g0[j] : g1[j - 4];
         const float b = j < 4 ? b0[j] : b1[j - 4];
         float y = (r.v[i][j] - mean) * rstd * g + b;
-        if (drop) y = stonk_keep((uint32_t)(row_idx * H + c * 8 + j), seed, thr24) ? y * dscale : 0.f;
+        if (drop) y = stonk_keep((uint32_t)row_idx, (uint32_t)(c * 8 + j), seed, thr32) ? y * dscale : 0.f;
         o[j] = (bf16)y;
       }
       *(bf16x8*)(yrow + c * 8) = o;
@@ -135,7 +135,7 @@ template <int CPL>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            long rows, int H, float eps, int flags, uint32_t thr24,
+                                                            long rows, int H, float eps, int flags, uint32_t thr32,
                                                             float dscale, uint32_t seed) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = H >> 3;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16* __restri
       mean_out[row] = mean;
       rstd_out[row] = rstd;
     }
-    normalize_store<CPL>(r, nch, lane, mean, rstd, gamma, beta, y + row * H, row, H, flags & STONK_LN_DROPOUT, thr24,
+    normalize_store<CPL>(r, nch, lane, mean, rstd, gamma, beta, y + row * H, row, H, flags & STONK_LN_DROPOUT, thr32,
                          dscale, seed);
   }
 }
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const bf16* __restrict__ dy, const bf16* __restrict__ x, const float* __restrict__ mean_in,
     const float* __restrict__ rstd_in, const float* __restrict__ gamma, bf16* __restrict__ dx,
     bf16* __restrict__ dx_drop, float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int H, int flags,
-    uint32_t thr24_in, float dscale_in, uint32_t seed_in, uint32_t thr24_out, float dscale_out, uint32_t seed_out,
+    uint32_t thr32_in, float dscale_in, uint32_t seed_in, uint32_t thr32_out, float dscale_out, uint32_t seed_out,
     float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float sred[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         for (int j = 0; j < 8; ++j) {
           float d = rd.v[i][j];
           if (flags & STONK_LN_DROPOUT)
-            d = stonk_keep((uint32_t)(row * H + c * 8 + j), seed_in, thr24_in) ? d * dscale_in : 0.f;
+            d = stonk_keep((uint32_t)row, (uint32_t)(c * 8 + j), seed_in, thr32_in) ? d * dscale_in : 0.f;
           const float xh = (rx.v[i][j] - mean) * rstd;
           ag[i][j] += d * xh;
           ab[i][j] += d;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
           const float v = rstd * (rd.v[i][j] - c1 - rx.v[i][j] * c2);
           o[j] = (bf16)v;
           if (dx_drop)
-            od[j] = (bf16)(stonk_keep((uint32_t)(row * H + c * 8 + j), seed_out, thr24_out) ? v * dscale_out : 0.f);
+            od[j] = (bf16)(stonk_keep((uint32_t)row, (uint32_t)(c * 8 + j), seed_out, thr32_out) ? v * dscale_out : 0.f);
         }
         *(bf16x8*)(dx + row * H + c * 8) = o;
         if (dx_drop) *(bf16x8*)(dx_drop + row * H + c * 8) = od;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void joint_embed_ln_kernel(
     const float* __restrict__ kg_table, const float* __restrict__ pos_emb, const float* __restrict__ type_emb,
     const float* __restrict__ gamma, const float* __restrict__ beta, bf16* __restrict__ sum_out, bf16* __restrict__ y,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, int B, int S, int half, int H, long kg_rows,
-    int type_rows, float eps, int flags, uint32_t thr24, float dscale, uint32_t seed, int* __restrict__ err) {
+    int type_rows, float eps, int flags, uint32_t thr32, float dscale, uint32_t seed, int* __restrict__ err) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = H >> 3;
   const long rows = (long)B * S;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void joint_embed_ln_kernel(
       mean_out[row] = mean;
       rstd_out[row] = rstd;
     }
-    normalize_store<CPL>(r, nch, lane, mean, rstd, gamma, beta, y + row * H, row, H, flags & STONK_LN_DROPOUT, thr24,
+    normalize_store<CPL>(r, nch, lane, mean, rstd, gamma, beta, y + row * H, row, H, flags & STONK_LN_DROPOUT, thr32,
                          dscale, seed);
   }
 }
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void text_embed_ln_kernel(const long* __restri
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16* __restrict__ y, int B,
                                                             int S, int H, long vocab, float eps, int flags,
-                                                            uint32_t thr24, float dscale, uint32_t seed,
+                                                            uint32_t thr32, float dscale, uint32_t seed,
                                                             int* __restrict__ err) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = H >> 3;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void text_embed_ln_kernel(const long* __restri
     add_f32_row<CPL>(type_emb, nch, lane, r);
     float mean, rstd;
     row_stats<CPL>(r, nch, lane, H, eps, mean, rstd);
-    normalize_store<CPL>(r, nch, lane, mean, rstd, gamma, beta, y + row * H, row, H, flags & STONK_LN_DROPOUT, thr24,
+    normalize_store<CPL>(r, nch, lane, mean, rstd, gamma, beta, y + row * H, row, H, flags & STONK_LN_DROPOUT, thr32,
                          dscale, seed);
   }
 }
@@ -413,11 +413,11 @@ extern "C" int stonk_layernorm_fwd(const void* x, const float* gamma, const floa
   STONK_CHECK_ARG(rows >= 0 && H > 0 && H % 8 == 0 && H <= 4096, STONK_ESHAPE);
   STONK_CHECK_ARG((mean == nullptr) == (rstd == nullptr), STONK_EINVAL);
   if (rows == 0) return STONK_OK;
-  const uint32_t thr = stonk_drop_thr24(drop_p);
+  const uint32_t thr = stonk_drop_thr32(drop_p);
   const float ds = 1.f / (1.f - drop_p);
   LN_DISPATCH(H, hipLaunchKernelGGL((layernorm_fwd_kernel<CPL>), dim3(ln_grid(rows)), dim3(256), 0,
                                     (hipStream_t)stream, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, (long)rows,
-                                    H, eps, flags, thr, ds, seed));
+                                    H, eps, flags, thr, ds, stonk_seed_mix(seed)));
   return stonk_launch_status();
 }
 
@@ -436,9 +436,9 @@ extern "C" int stonk_layernorm_bwd(const void* dy, const void* x, const float* m
   float* ws = (dgamma && partial_ws && ws_floats >= (int64_t)grid * 2 * H) ? partial_ws : nullptr;
   LN_DISPATCH(H, hipLaunchKernelGGL((layernorm_bwd_kernel<CPL>), dim3(grid), dim3(256), lds, (hipStream_t)stream,
                                     (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (bf16*)dx, (bf16*)dx_drop,
-                                    dgamma, dbeta, (long)rows, H, flags, stonk_drop_thr24(drop_p_in),
-                                    1.f / (1.f - drop_p_in), seed_in, stonk_drop_thr24(drop_p_out),
-                                    1.f / (1.f - drop_p_out), seed_out, ws));
+                                    dgamma, dbeta, (long)rows, H, flags, stonk_drop_thr32(drop_p_in),
+                                    1.f / (1.f - drop_p_in), stonk_seed_mix(seed_in), stonk_drop_thr32(drop_p_out),
+                                    1.f / (1.f - drop_p_out), stonk_seed_mix(seed_out), ws));
   if (ws)
     hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((2 * H + 255) / 256, 32), dim3(256), 0, (hipStream_t)stream, ws, grid,
                        H, dgamma, dbeta);
@@ -461,7 +461,7 @@ extern "C" int stonk_joint_embed_ln_fwd(const int64_t* input_ids, const int64_t*
                                     (hipStream_t)stream, (const long*)input_ids, (const long*)token_type_ids,
                                     (const bf16*)text_hidden, kg_table, pos_emb, type_emb, gamma, beta,
                                     (bf16*)sum_out, (bf16*)y, mean, rstd, B, S, half, H, (long)kg_rows, type_rows, eps,
-                                    flags, stonk_drop_thr24(drop_p), 1.f / (1.f - drop_p), seed, err_flag));
+                                    flags, stonk_drop_thr32(drop_p), 1.f / (1.f - drop_p), stonk_seed_mix(seed), err_flag));
   return stonk_launch_status();
 }
 
@@ -476,7 +476,7 @@ extern "C" int stonk_text_embed_ln_fwd(const int64_t* input_ids, int64_t ld_ids,
   LN_DISPATCH(H, hipLaunchKernelGGL((text_embed_ln_kernel<CPL>), dim3(ln_grid(rows)), dim3(256), 0,
                                     (hipStream_t)stream, (const long*)input_ids, (long)ld_ids, word_emb, pos_emb,
                                     type_emb, gamma, beta, (bf16*)y, B, S, H, (long)vocab, eps, flags,
-                                    stonk_drop_thr24(drop_p), 1.f / (1.f - drop_p), seed, err_flag));
+                                    stonk_drop_thr32(drop_p), 1.f / (1.f - drop_p), stonk_seed_mix(seed), err_flag));
   return stonk_launch_status();
 }
 

@@ -157,9 +157,9 @@ extern "C" int stonk_gelu_bwd_bf16(const void* dg, const void* u, void* du, int6
 // ref:src/stonkgs/models/stonkgs_finetuning.py:313); the same call with the same (seed) replays the mask on the gradient.
 namespace {
 __global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
-                                                          uint32_t thr24, float scale, uint32_t seed) {
+                                                          uint32_t thr32, float scale, uint32_t seed) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-    y[i] = stonk_keep((uint32_t)i, seed, thr24) ? x[i] * scale : 0.f;
+    y[i] = stonk_keep(0u, (uint32_t)i, seed, thr32) ? x[i] * scale : 0.f;
 }
 __global__ void ratio_kernel(const float* num, const float* den, float* out) { *out = *num / *den; }
 }  // namespace
@@ -169,7 +169,7 @@ extern "C" int stonk_dropout_f32(const float* x, float* y, int64_t n, float p, u
   if (n == 0) return STONK_OK;
   const long g = (n + 255) / 256;
   hipLaunchKernelGGL(dropout_f32_kernel, dim3((unsigned)(g < 1024 ? g : 1024)), dim3(256), 0, (hipStream_t)stream, x, y,
-                     (long)n, stonk_drop_thr24(p), 1.f / (1.f - p), seed);
+                     (long)n, stonk_drop_thr32(p), 1.f / (1.f - p), stonk_seed_mix(seed));
   return stonk_launch_status();
 }
 

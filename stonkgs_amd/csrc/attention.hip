@@ -55,7 +55,14 @@ struct AttnArgs {
   uint32_t seed;      // mixed (stonk_seed_mix)
 };
 
-__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+// 16-byte chunk swizzle of a 128-byte tile row. Rows 2t and 2t+1 sit in opposite bank halves and share a swizzle; the
+// swizzle is a bit rotation of t so that (a) 16 consecutive rows reading one logical chunk (ds_read_b128 fragments) hit
+// 16 different bank groups and (b) rows r and r+2 of a transposed 4-row x 64-byte read (ds_read_b64_tr_b16) fall into
+// different chunk halves - with the plain (row >> 1) & 7 they collided two ways (SQ_LDS_BANK_CONFLICT 20 % of LDS cycles).
+__device__ __forceinline__ int swz(int row) {
+  const int t = (row >> 1) & 7;
+  return ((t & 1) << 2) | (t >> 1);
+}
 // byte offset of element (row, col) inside a [64][64] bf16 tile image
 __device__ __forceinline__ int tile_off(int row, int col) {
   return row * ROWB + ((((col >> 3) ^ swz(row)) << 4) | ((col & 7) << 1));

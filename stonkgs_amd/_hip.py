@@ -25,6 +25,7 @@ EPI_DROPOUT = 1 << 7
 EPI_DEBUG_REGSTAGE = 1 << 16
 EPI_DEBUG_V1 = 1 << 17
 EPI_DEBUG_V2 = 1 << 18
+EPI_DEBUG_W4 = 1 << 20
 LN_DROPOUT = 1 << 0
 SMALL_TANH = 1
 SMALL_X_F32 = 16

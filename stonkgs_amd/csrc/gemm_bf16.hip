@@ -19,6 +19,7 @@ using namespace stonk_gemm;
 
 // defined in gemm256.hip
 int stonk_gemm256_launch(const GemmArgs& a, int out_mode, hipStream_t st);
+int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, hipStream_t st);
 
 namespace {
 
@@ -327,6 +328,14 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
                       (!(flags & STONK_EPI_RESID) || (ldr % 8 == 0 && (uintptr_t)resid % 16 == 0)) &&
                      (!(flags & (STONK_EPI_SAVE_PREACT | STONK_EPI_GELU_BWD)) ||
                       (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0));
+  // the four-wave kernel walks K tiles in pairs: an even number per work item
+  // ... and addresses its operands with 32-bit byte offsets from a per-K-tile base, chunk-swizzled by XOR (ld % 64)
+  const bool w4_ok = ldc % 8 == 0 && !both_sides && (K / BK) % (2 * split_k) == 0 && !k_dev && lda % 64 == 0 &&
+                     ldb % 64 == 0 && (long)M * lda < (1L << 30) && (long)N * ldb < (1L << 30) && M >= 8 && M % 8 == 0 &&
+                     (!(flags & STONK_EPI_RESID) || (ldr % 8 == 0 && (uintptr_t)resid % 16 == 0)) &&
+                     (!(flags & (STONK_EPI_SAVE_PREACT | STONK_EPI_GELU_BWD)) ||
+                      (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0));
+  if (w4_ok && (flags & STONK_EPI_DEBUG_W4)) return stonk_gemm_w4_launch(a, out_mode, st);
   if (v2_ok && !(flags & (STONK_EPI_DEBUG_V1 | STONK_EPI_DEBUG_REGSTAGE)) && (big || (flags & STONK_EPI_DEBUG_V2)))
     return stonk_gemm256_launch(a, out_mode, st);
   const long tiles = (long)((M + BM - 1) / BM) * (N / BN) * split_k;

@@ -15,6 +15,7 @@
 #define STONK_EPI_DEBUG_V1 (1 << 17)       /* force the 128x128 two-barrier kernel */
 #define STONK_EPI_DEBUG_V2 (1 << 18)       /* force the persistent 256x256 kernel */
 #define STONK_EPI_DEBUG_SIDE_V1 (1 << 19)  /* A/B test: keep side-operand epilogues on the 128x128 kernel */
+#define STONK_EPI_DEBUG_W4 (1 << 20)       /* force the four-wave 256x256 kernel (gemm_w4.hip) */
 // --- stonk_layernorm_* `flags` ---
 #define STONK_LN_DROPOUT (1 << 0)
 // --- stonk_small_linear_* `act` ---

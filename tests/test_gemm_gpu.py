@@ -24,7 +24,7 @@ def _rand(shape, scale=1.0, seed=0):
     return (torch.randn(shape, device="cuda", generator=g) * scale).to(torch.bfloat16)
 
 
-KERNELS = {"v1": 1 << 17, "v1_regstage": 1 << 16, "v2_256": 1 << 18, "auto": 0}
+KERNELS = {"v1": 1 << 17, "v1_regstage": 1 << 16, "v2_256": 1 << 18, "w4_256": 1 << 20, "auto": 0}
 
 
 @pytest.mark.parametrize("kernel", list(KERNELS))
@@ -51,9 +51,9 @@ def test_gemm_asymmetric_identity(hip):
     torch.testing.assert_close(out, B.float().t().contiguous(), rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("dbg", [1 << 17, 1 << 18])
+@pytest.mark.parametrize("dbg", [1 << 17, 1 << 18, 1 << 20])
 def test_gemm_epilogues(hip, dbg):
-    M, N, K = 300, 256, 192
+    M, N, K = (304, 256, 256) if dbg == 1 << 20 else (300, 256, 192)   # four-wave kernel: K tiles in pairs, M % 8
     A, B = _rand((M, K), 0.5, 3), _rand((N, K), 0.5, 4)
     bias = torch.randn(N, device="cuda")
     resid = _rand((M, N), 1.0, 5)
@@ -75,6 +75,7 @@ def test_gemm_epilogues(hip, dbg):
 
 
 @pytest.mark.parametrize("dbg,M,N,K,sk", [(1 << 17, 256, 128, 2048, 8), (1 << 18, 768, 768, 8192, 7),
+                                          (1 << 20, 768, 768, 8192, 8), (1 << 20, 304, 512, 4096, 16),
                                           (1 << 18, 300, 256, 4096, 32), (0, 3072, 768, 32768, 8)])
 def test_gemm_splitk_atomic_accumulates(hip, dbg, M, N, K, sk):
     A, B = _rand((M, K), 0.3, 7), _rand((N, K), 0.3, 8)
@@ -107,6 +108,40 @@ def test_gemm256_device_counts_and_races(hip):
     torch.testing.assert_close(first.float(), A3.float() @ B3.float().t(), rtol=2e-2, atol=2e-2)
     for _ in range(20):
         assert torch.equal(_gemm(hip, A3, B3, flags=hip.EPI_DEBUG_V2), first)
+
+
+def test_gemm_w4_device_rows_races_and_fused_epilogue(hip):
+    """Four-wave 256x256 kernel: device-side M with a ragged last tile, many work items per workgroup, bit-identical
+    repeats (a ring-slot race would show as rare differing tiles), and the bias + dropout + residual epilogue."""
+    W4 = 1 << 20
+    M, N, K = 16384, 768, 1024
+    A, B = _rand((M, K), 0.5, 31), _rand((N, K), 0.5, 32)
+    m_dev = torch.tensor([2432 - 5], device="cuda", dtype=torch.int32)
+    C = torch.full((M, N), -7.0, device="cuda")
+    _gemm(hip, A, B, flags=W4 | hip.EPI_OUT_F32, C=C, m_dev=m_dev)
+    torch.testing.assert_close(C[:2427], A[:2427].float() @ B.float().t(), rtol=1e-4, atol=2e-3)
+    assert (C[2427:] == -7.0).all()
+    A3, B3 = _rand((8192, 768), 1.0, 35), _rand((3072, 768), 0.05, 36)
+    first = _gemm(hip, A3, B3, flags=W4)
+    torch.testing.assert_close(first.float(), A3.float() @ B3.float().t(), rtol=2e-2, atol=2e-2)
+    for _ in range(20):
+        assert torch.equal(_gemm(hip, A3, B3, flags=W4), first)
+    # N = 768 output with K = 3072 (FFN down): bias + dropout + residual, compared through the kept elements
+    A4, B4 = _rand((4096, 3072), 0.5, 37), _rand((768, 3072), 0.05, 38)
+    bias = torch.randn(768, device="cuda")
+    resid = _rand((4096, 768), 1.0, 39)
+    fl = W4 | hip.EPI_BIAS | hip.EPI_RESID | hip.EPI_DROPOUT
+    out = _gemm(hip, A4, B4, flags=fl, bias=bias, resid=resid, drop_p=0.1, seed=77).float()
+    pre = A4.float() @ B4.float().t() + bias
+    delta = out - resid.float()                      # = keep ? pre / 0.9 : 0
+    kept = (delta.abs() > 1e-3) | (pre.abs() < 1e-2)
+    assert abs(1.0 - kept.float().mean().item() - 0.1) < 0.01
+    torch.testing.assert_close(torch.where(kept, delta, torch.zeros_like(delta)),
+                               torch.where(kept, pre / 0.9, torch.zeros_like(pre)), rtol=3e-2, atol=6e-2)
+    # same mask from the 128x128 kernel (one dropout stream per (seed, row, column), whatever the tiling)
+    out_v1 = _gemm(hip, A4, B4, flags=(1 << 17) | hip.EPI_BIAS | hip.EPI_RESID | hip.EPI_DROPOUT, bias=bias,
+                   resid=resid, drop_p=0.1, seed=77).float()
+    assert ((out_v1 - resid.float()).abs() > 1e-3).eq((delta.abs() > 1e-3)).float().mean().item() > 0.999
 
 
 def test_gemm_device_row_count_and_dropout(hip):

@@ -29,7 +29,7 @@ def bench_gemm():
         A = (torch.randn(M, K, device="cuda")).to(torch.bfloat16)
         B = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
         C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-        for name, dbg in (("v1_128", hip.EPI_DEBUG_V1), ("v2_256", hip.EPI_DEBUG_V2)):
+        for name, dbg in (("v1_128", hip.EPI_DEBUG_V1), ("v2_256", hip.EPI_DEBUG_V2), ("w4_256", hip.EPI_DEBUG_W4)):
             def f():
                 hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, M, N, K, dbg, 0, 0, 0, 0, 0,
                          1.0, 1, 0, 0, 0.0, 0, hip.stream_ptr())

@@ -13,6 +13,8 @@
 // Operand tiles are staged global->LDS with 16-byte LDS-DMA (global_load_lds_dwordx4), double buffered;
 // the LDS image is lane-linear, the XOR swizzle (chunk ^ (row & 7)) is applied on the per-lane SOURCE
 // address and again on the ds_read_b128 fragment reads (conflict-free for 128-byte rows).
+#include <cstdlib>
+
 #include "gemm_common.h"
 
 using namespace stonk_gemm;
@@ -331,7 +333,7 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   // the four-wave kernel walks K tiles in pairs: an even number per work item
   // ... and addresses its operands with 32-bit byte offsets from a per-K-tile base, chunk-swizzled by XOR (ld % 64)
   const bool w4_ok = ldc % 8 == 0 && !both_sides && (K / BK) % (2 * split_k) == 0 && !k_dev && lda % 64 == 0 &&
-                     ldb % 64 == 0 && (long)M * lda < (1L << 30) && (long)N * ldb < (1L << 30) && M >= 8 && M % 8 == 0 &&
+                     ldb % 64 == 0 && (long)M * lda < (1L << 30) && (long)N * ldb < (1L << 30) && (long)M * ldc < (1L << 28) &&
                      (!(flags & STONK_EPI_RESID) || (ldr % 8 == 0 && (uintptr_t)resid % 16 == 0)) &&
                      (!(flags & (STONK_EPI_SAVE_PREACT | STONK_EPI_GELU_BWD)) ||
                       (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0));

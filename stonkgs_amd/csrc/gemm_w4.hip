@@ -3,26 +3,29 @@
 // (C = epilogue(alpha * A[M,K] . B[N,K]^T)).
 //
 // Why a third tiling: in the eight-wave kernel (gemm256.hip, wave tile 128x64) every K tile costs the CU 192 KiB of
-// fragment reads + 64 KiB of LDS-DMA writes = 2048 LDS cycles at 128 B/clk - exactly the 2048 MFMA cycles of the K
-// tile, so the matrix pipe can never be more than about half busy. A 128x128 wave tile reads 128 KiB per K tile
-// (75 % of the LDS budget with the DMA writes), which is what the vendor library's 256x256 kernels do as well.
+// fragment reads + 64 KiB of LDS writes = 2048 LDS cycles at 128 B/clk - exactly the 2048 MFMA cycles of the K tile, so
+// the matrix pipe can never be much more than half busy. A 128x128 wave tile reads 128 KiB per K tile (75 % of the LDS
+// budget with the writes), which is what the vendor library's 256x256 kernels do as well.
 //
-// Schedule. A K tile is staged as four 16 KiB half-tiles cut by use (A-first = rows 0-63 of each wave-row's 128,
-// B-first = columns 0-63 of each wave-column's 128, B-second, A-second), in a ring of EIGHT slots (two K tiles). A K
-// tile is four phases of 16 MFMAs, one 64x64 quadrant each: (A0,B0) (A0,B1) (A1,B1) (A1,B0). With half-tiles numbered
-// h = 4t + {0 A-first, 1 B-first, 2 B-second, 3 A-second} and phases phi = 4t + p, phase phi
-//   * multiplies the quadrant whose fragments are already in registers,
-//   * reads half-tile phi+2 from LDS into the fragment registers the NEXT phase needs (8 ds_read_b128),
-//   * DMAs half-tile phi+9 (global_load_lds_dwordx4, 4 per wave) into the slot that phase phi-1 finished reading,
-//   * ends with  s_waitcnt lgkmcnt(0) ; s_waitcnt vmcnt(24) ; s_barrier : half-tile phi+3 has landed (six younger
-//     half-tiles = 24 DMA instructions stay in flight, about 1.5 us of prefetch distance) and every wave is done reading
-//     the slot the next phase refills.
-// B-first fragments are kept from phase 0 to phase 3, so the two B register sets swap roles every K tile (the K loop is
-// unrolled by two; slot numbers are compile-time constants of (phase, parity)).
-// The prefetch cursor runs across output tiles, and because it is seven half-tiles ahead, the waits of the six phases
-// after a tile boundary simply count the epilogue's stores on top (vmcnt retires in order): no drain, no special
-// boundary protocol. When the cursor runs out of work it re-reads its last position (never consumed), so the wait
-// counts stay constant to the end.
+// Operands travel global -> registers -> LDS -> fragment registers. With one wave per SIMD every instruction the wave
+// issues competes with its own MFMAs, and an LDS-DMA piece (global_load_lds_dwordx4) costs the issuing wave 60+ cycles
+// - measured on the first version of this kernel as 240 us of a 1017 us 8192^3 run (STONK_W4_VAR experiments) - where a
+// plain 16-byte load and a ds_write_b128 cost a few cycles each.
+//
+// Schedule. The two K-tile stages (A image 256 rows x 128 B + B image, XOR-swizzled, 64 KiB each) alternate; a K tile
+// is consumed in four k steps of 16 MFMAs (4 x 4 blocks, 16 different accumulators: no MFMA waits for its predecessor).
+// k step (t, ks)
+//   * multiplies with the fragments read during the previous k step (two fragment sets of 8 x ds_read_b128 alternate:
+//     only 64 fragment registers are live, against 128 for a quadrant-by-quadrant order),
+//   * reads the fragments of the next k step - for ks = 3 those of K tile t+1, from the other stage,
+//   * writes four 1 KiB pieces (8 rows x 128 B) of K tile t+1 (ks = 3: t+2) from staging registers to the other stage,
+//     behind ONE counted wait, vmcnt(12): the loads of the three younger k steps stay in flight (about 2000 cycles),
+//   * loads the four pieces that the same k step of the NEXT K tile will write into those staging registers.
+// One s_barrier per K tile, after k step 2: K tile t+1 is then complete in its stage (k step 3 may read it) and every
+// wave is done reading K tile t-1's... i.e. the stage that k step 3 starts to refill.
+// After a tile boundary the wait counts the epilogue's stores on top for four k steps (vmcnt retires in order), so the
+// load stream never drains. The prefetch cursor runs across output tiles; when it runs out of work it re-reads its
+// last position (never consumed), so the counts stay constant to the end.
 #include <cstdlib>
 
 #include "gemm_common.h"
@@ -32,8 +35,9 @@ using namespace stonk_gemm;
 namespace {
 
 constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int HALF_BYTES = 128 * BK * 2;            // 16 KiB
-constexpr int LDS_RING = 8 * HALF_BYTES;            // 128 KiB
+constexpr int IMG_BYTES = 256 * BK * 2;             // one operand of one K tile: 32 KiB
+constexpr int STAGE_BYTES = 2 * IMG_BYTES;          // 64 KiB
+constexpr int LDS_RING = 2 * STAGE_BYTES;           // 128 KiB
 constexpr int SLAB_BYTES = 32 * 64 * 4;             // per wave: 32 rows x 64 fp32 columns
 constexpr int LDS_BYTES = LDS_RING + 4 * SLAB_BYTES;  // 160 KiB
 
@@ -53,8 +57,8 @@ __device__ __forceinline__ void wait_vm() {
 }
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// VAR: timing experiments only (bit 0 no barrier, bit 1 all fragment reads in the first two sub-steps, bit 2 no DMA in the
-// loop, bit 3 no fragment reads in the loop) - anything but 0 / 2 computes garbage.
+// VAR: timing experiments only (bit 0 no barrier, bit 2 no global loads / LDS writes in the loop, bit 3 no fragment
+// reads in the loop, bit 4 loads but no LDS writes, bit 5 LDS writes but no loads) - anything but 0 computes garbage.
 template <int OUT_MODE, int EPI, int VAR = 0>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -107,83 +111,73 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     return true;
   };
 
-  // ---- DMA: half-tile image = 128 rows x 128 B; wave w moves image rows [32w, 32w+32) in four 1 KiB pieces (8 rows
-  // each). LDS-DMA writes lane-linearly, so lane -> (row l8 = lane>>3, physical chunk lane&7) and the XOR swizzle
-  // (physical = logical ^ ((row >> 1) & 7)) is applied to the SOURCE chunk. One wave per SIMD means every bookkeeping
-  // instruction competes with the MFMAs for the wave's single issue stream, so a piece costs NO vector arithmetic: its
-  // address is a uniform 64-bit base (SALU: cursor base + first row of the piece * ld) plus one of four loop-invariant
-  // per-lane offsets (l8 * ld + swizzled chunk; the odd pieces' chunk is the even pieces' ^ 64). Pieces that would
-  // start past the last 8 rows of the operand are pulled back to it as a whole (valid memory; such rows are never
-  // stored). The launcher guarantees rows * ld * 2 < 2^31, ld % 64 == 0 and at least 8 rows.
+  // ---- global -> staging registers. A K tile of one operand = 256 rows x 128 B = 32 pieces of 8 rows; wave w moves
+  // pieces 8w..8w+7 of A and of B: 16 pieces per K tile, four per k step. Lane -> (row l8 = lane>>3, chunk lane&7 of the
+  // LDS image); the image is XOR-swizzled (physical chunk = logical ^ ((row >> 1) & 7)) by permuting the SOURCE chunks,
+  // so the LDS write is lane-linear. One wave per SIMD means address arithmetic competes with the MFMAs for the wave's
+  // single issue stream (the first version spent 18 % of its cycles on SALU), so a piece costs none: buffer loads take
+  // one of two loop-invariant per-lane byte offsets per operand ((64 wave + l8) * ld + swizzled chunk) plus a scalar
+  // offset (tile origin * ld + K offset, bumped by 128 per K tile, + piece * 8 * ld: one SALU add), and rows past the
+  // operand's end read as zeros by the buffer's range check - no clamping. The launcher guarantees rows * ld * 2 < 2^31 and ld % 64 == 0.
   const int l8 = lane >> 3;
   const int lda2 = (int)p.lda * 2, ldb2 = (int)p.ldb * 2;
-  uint32_t voffA[2], voffB[2];
+  int voffA[2], voffB[2];   // even / odd pieces (the odd pieces' swizzled chunk is the even pieces' ^ 64)
   {
-    const uint32_t c0 = (uint32_t)(((lane & 7) ^ (l8 >> 1)) * 16);
-    voffA[0] = (uint32_t)(l8 * lda2) + c0;
-    voffA[1] = (uint32_t)(l8 * lda2) + (c0 ^ 64u);
-    voffB[0] = (uint32_t)(l8 * ldb2) + c0;
-    voffB[1] = (uint32_t)(l8 * ldb2) + (c0 ^ 64u);
+    const int c0 = ((lane & 7) ^ (l8 >> 1)) * 16;
+    voffA[0] = (wave * 64 + l8) * lda2 + c0;
+    voffA[1] = (wave * 64 + l8) * lda2 + (c0 ^ 64);
+    voffB[0] = (wave * 64 + l8) * ldb2 + c0;
+    voffB[1] = (wave * 64 + l8) * ldb2 + (c0 ^ 64);
   }
-  const int wave_lds = wave * 4096;
-  const int wave_origin = (wave >> 1) * 128 + (wave & 1) * 32;
-  const char* curA = (const char*)p.A;   // operand bases advanced to the K tile the prefetch cursor points at
-  const char* curB = (const char*)p.B;
-  int p_m0 = 0, p_n0 = 0;
+  const int pstepA = 8 * lda2, pstepB = 8 * ldb2;   // byte distance between consecutive pieces (uniform)
+  // (An inline-asm variant of these loads, whose waits are all hand-counted, removes the compiler's conservative wait
+  // after a tile boundary - pending loads are older than the epilogue's stores, and vmcnt retires in order - but the
+  // compiler then spills in-flight staging registers around the epilogue: not shippable. See DESIGN.md section 4.2.)
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.M * lda2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, N * ldb2, 0x00020000);
+  const int wofs = wave * 8192 + lane * 16;   // this lane's 16 bytes of piece 0 of this wave inside an operand image
+  int soffA = 0, soffB = 0;   // scalar byte offsets of the K tile the prefetch cursor points at
   auto set_sources = [&](const Work& w) {
-    p_m0 = w.m0;
-    p_n0 = w.n0;
-    curA = (const char*)p.A + w.k_begin * 2;
-    curB = (const char*)p.B + w.k_begin * 2;
+    soffA = w.m0 * lda2 + (int)w.k_begin * 2;
+    soffB = w.n0 * ldb2 + (int)w.k_begin * 2;
   };
-  // kind: 0 A-first, 1 B-first, 2 B-second, 3 A-second
-  auto issue_piece = [&](const int kind, const int slot, const int i) {
-    int wl = wave_lds, wo = wave_origin;
-    asm volatile("" : "+s"(wl), "+s"(wo));   // opaque: destinations are re-derived here, not kept in 32 SGPRs
-    char* dst = smem + wl + slot * HALF_BYTES + i * 1024;
-    const bool isA = (kind == 0 || kind == 3);
-    const bool second = kind >= 2;
-    int row0 = (isA ? p_m0 : p_n0) + wo + (second ? 64 : 0) + i * 8;
-    const int last = (isA ? p.M : N) - 8;
-    row0 = row0 < last ? row0 : last;
-    const char* base = (isA ? curA : curB) + (long)(row0 * (isA ? lda2 : ldb2));
-    const uint32_t voff = isA ? voffA[i & 1] : voffB[i & 1];
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff),
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  // piece q of this wave: q < 8 -> A rows 64 wave + 8 q .., q >= 8 -> B rows 64 wave + 8 (q - 8) ..
+  auto load_piece = [&](const int q, bf16x8& d) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const u32x4 v = (q < 8) ? __builtin_amdgcn_raw_buffer_load_b128(rsrcA, voffA[q & 1], soffA + (q & 7) * pstepA, 0)
+                            : __builtin_amdgcn_raw_buffer_load_b128(rsrcB, voffB[q & 1], soffB + (q & 7) * pstepB, 0);
+    d = __builtin_bit_cast(bf16x8, v);
   };
-  auto issue = [&](const int kind, const int slot) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) issue_piece(kind, slot, i);
+  auto write_piece = [&](const int stage, const int q, const bf16x8& d) {
+    *(bf16x8*)(smem + stage * IMG_BYTES + (q < 8 ? 0 : 2 * IMG_BYTES) + (q & 7) * 1024 + wofs) = d;
   };
+  bf16x8 stg[4][4];   // [k step][piece]: loaded in k step ks of one K tile, written in k step ks of the next
 
   // ---- fragment reads: lane (r = lane & 31, hh = lane >> 5) takes row r of a 32-row block, k = 16 ks + 8 hh .. +7
   const int r = lane & 31, hh = lane >> 5;
-  int lofs[4];
+  int lofsA[4], lofsB[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) lofs[ks] = r * 128 + (((2 * ks + hh) ^ ((r >> 1) & 7)) << 4);
-  const int a_base = wr * 8192, b_base = wc * 8192;   // this wave's 64 image rows of an A / B half
-  bf16x8 fa0[2][4], fa1[2][4], fb[2][2][4];            // [row block][k step]
-  auto read_half = [&](const int slot, const int wbase, bf16x8 (&f)[2][4]) {
-    const char* s = smem + slot * HALF_BYTES + wbase;
+  for (int ks = 0; ks < 4; ++ks) {
+    const int o = r * 128 + (((2 * ks + hh) ^ ((r >> 1) & 7)) << 4);
+    lofsA[ks] = o + wr * 16384;               // this wave's 128 rows of the A image
+    lofsB[ks] = o + wc * 16384 + 2 * IMG_BYTES;   // ... and of the B image (A images at 0 / 32 KiB, B at 64 / 96 KiB:
+                                                  // either stage is within a 16-bit immediate of these two bases)
+  }
+  bf16x8 fr[2][8];   // [set][0-3: A row blocks, 4-7: B column blocks]
+  auto read_frags = [&](const int stage, const int ks, bf16x8 (&f)[8]) {
+    const char* s = smem + stage * IMG_BYTES;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) f[rb][ks] = *(const bf16x8*)(s + rb * 4096 + lofs[ks]);
+    for (int b = 0; b < 4; ++b) {
+      f[b] = *(const bf16x8*)(s + b * 4096 + lofsA[ks]);
+      f[4 + b] = *(const bf16x8*)(s + b * 4096 + lofsB[ks]);
+    }
   };
 
-  f32x16 acc[2][2][2][2];   // [A half][B half][32-row block][32-col block]
-  auto zero_acc = [&]() {
+  f32x16 acc[4][4];   // [32-row block][32-column block]
+  f32x16 fzero;   // first k step of a work item: C = 0 as the MFMA's inline constant (no 256-register clear)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][i][j][e] = 0.f;
-  };
+  for (int e = 0; e < 16; ++e) fzero[e] = 0.f;
+
   // ------------------------------------------------------------------ stream state
   Work cw, pw;
   int cwi = blockIdx.x;
@@ -197,13 +191,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   int pk = 0;
   bool p_valid = true;
   set_sources(pw);
-  // advance the prefetch cursor by one K tile (after its A-second half-tile has been issued)
+  // advance the prefetch cursor by one K tile (after its last pieces have been requested)
   auto advance_prefetch = [&]() {
     if (!p_valid) return;   // out of work: the cursor keeps re-reading its last K tile (valid memory, never consumed)
     if (pk + 1 < pw.nk) {
       ++pk;
-      curA += BK * 2;
-      curB += BK * 2;
+      soffA += BK * 2;
+      soffB += BK * 2;
       return;
     }
     Work nw;
@@ -223,192 +217,220 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     set_sources(pw);
   };
 
-  // epilogue vm operations that can still be outstanding during the six phases after a tile boundary
+  // epilogue vm operations that can still be outstanding during the four k steps after a tile boundary
   constexpr int FL = EPI >= 0 ? EPI : 0;
   constexpr int S = (OUT_MODE == 0) ? ((FL & STONK_EPI_SAVE_PREACT) || EPI < 0 ? 64 : 32) : (OUT_MODE == 1 ? 64 : 0);
-  constexpr int WAIT_POST = (24 + S) > 63 ? 63 : (24 + S);
-  auto phase_end = [&](const bool post) {
-    __builtin_amdgcn_sched_barrier(0);
-    wait_lgkm0();
-    if (post) wait_vm<WAIT_POST>();
-    else wait_vm<24>();
-    if (!(VAR & 1)) barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // One phase = four sub-steps, one 16-deep k step each: 4 MFMAs on four different accumulator blocks (so no MFMA
-  // waits for its predecessor's result), two of the next phase's fragment reads and one DMA piece, placed in the MFMA
-  // gaps (one wave per SIMD: the same wave has to feed the matrix pipe AND issue the loads). The sub-steps are fenced
-  // so the scheduler cannot chain the four k steps of one accumulator back to back.
-  auto phase = [&](f32x16 (&c)[2][2], const bf16x8 (&a)[2][4], const bf16x8 (&b)[2][4], const int rslot, const int rbase,
-                   bf16x8 (&f)[2][4], const int kind, const int islot) {
-    const char* rs = smem + rslot * HALF_BYTES + rbase;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (!(VAR & 8)) {
-        if (VAR & 2) {
-          if (ks < 2) {
-            f[0][2 * ks] = *(const bf16x8*)(rs + lofs[2 * ks]);
-            f[1][2 * ks] = *(const bf16x8*)(rs + 4096 + lofs[2 * ks]);
-            f[0][2 * ks + 1] = *(const bf16x8*)(rs + lofs[2 * ks + 1]);
-            f[1][2 * ks + 1] = *(const bf16x8*)(rs + 4096 + lofs[2 * ks + 1]);
-          }
-        } else {
-          f[0][ks] = *(const bf16x8*)(rs + lofs[ks]);
-          f[1][ks] = *(const bf16x8*)(rs + 4096 + lofs[ks]);
-        }
-      }
-      if (!(VAR & 4)) issue_piece(kind, islot, ks);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          // swapped operands: D[n][m] - a lane holds one output row m and groups of 4 consecutive columns
-          c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j][ks], a[i][ks], c[i][j], 0, 0, 0);
-        }
-      if (VAR & 2) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (ks < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (ks < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      } else {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // VALU: the DMA piece's address
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // the LDS-DMA (a VMEM read)
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
+  constexpr int WAIT_POST = (12 + S) > 63 ? 63 : (12 + S);
 
-  // ---- prologue: half-tiles 0..6, then the two read-only phases phi = -2, -1
-  issue(0, 0);
-  issue(1, 1);
-  issue(2, 2);
-  issue(3, 3);
-  advance_prefetch();
-  issue(0, 4);
-  issue(1, 5);
-  issue(2, 6);
-  wait_vm<24>();
-  barrier();
-  read_half(0, a_base, fa0);
-  issue(3, 7);
-  advance_prefetch();
-  phase_end(false);
-  read_half(1, b_base, fb[0]);
-  issue(0, 0);
-  phase_end(false);
-
-  // One K tile; PAR = parity of the K tile in the stream (selects ring stage and the B register roles).
-  // post01 / post23: phases 0-1 / 2-3 fall within the six phases after a tile boundary (waits count its stores too)
-#define STONK_W4_KTILE(PAR)                                                                                      \
-  do {                                                                                                           \
-    /* phase 0: (A0, B-first) ; read B-second ; DMA B-first of tile t+2 */                                       \
-    phase(acc[0][0], fa0, fb[PAR], (4 * (PAR) + 2) & 7, b_base, fb[(PAR) ^ 1], 1, (4 * (PAR) + 1) & 7);          \
-    phase_end(post01);                                                                                           \
-    /* phase 1: (A0, B-second) ; read A-second ; DMA B-second of t+2 */                                          \
-    phase(acc[0][1], fa0, fb[(PAR) ^ 1], (4 * (PAR) + 3) & 7, a_base, fa1, 2, (4 * (PAR) + 2) & 7);              \
-    phase_end(post01);                                                                                           \
-    /* phase 2: (A1, B-second) ; read A-first of t+1 ; DMA A-second of t+2, then the cursor moves on */          \
-    phase(acc[1][1], fa1, fb[(PAR) ^ 1], (4 * (PAR) + 4) & 7, a_base, fa0, 3, (4 * (PAR) + 3) & 7);              \
-    phase_end(post23);                                                                                           \
-    advance_prefetch();                                                                                          \
-    /* phase 3: (A1, B-first) ; read B-first of t+1 into the B-second registers ; DMA A-first of t+3 */          \
-    phase(acc[1][0], fa1, fb[PAR], (4 * (PAR) + 5) & 7, b_base, fb[(PAR) ^ 1], 0, (4 * (PAR) + 4) & 7);          \
-    phase_end(post23);                                                                                           \
+  // One k step. ST = stage of the K tile being multiplied, KS = k step. Pieces written here: 4 ((KS + 1) & 3) .. +3 of
+  // K tile t+1 (KS = 3: of t+2), into the stage not being multiplied... which for KS = 3 IS stage ST: safe, every wave
+  // passed this K tile's barrier (after k step 2) and so finished reading ST's last fragments.
+#define STONK_W4_KSTEP(ST, KS, FIRST)                                                                         \
+  do {                                                                                                 \
+    constexpr int WST = ((KS) == 3) ? (ST) : ((ST) ^ 1);                                               \
+    constexpr int Q0 = 4 * (((KS) + 1) & 3);                                                           \
+    constexpr int RST = ((KS) == 3) ? ((ST) ^ 1) : (ST);                                               \
+    constexpr int RKS = ((KS) + 1) & 3;                                                                \
+    if (!(VAR & 4) && !(VAR & 16)) {                                                                   \
+      if (post) wait_vm<WAIT_POST>();                                                                  \
+      else wait_vm<12>();                                                                              \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    /* four sub-blocks of 4 MFMAs (one accumulator row) with ONE memory instruction per MFMA gap: the next k step's \
+       A and B fragment of block g, one staged piece to LDS, one load (a ds_write_b128 or a buffer load occupies the \
+       wave's issue for 20-35 cycles - about what one 32-cycle MFMA hides, and no more) */                \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
+      if (!(VAR & 8)) {                                                                                \
+        fr[RKS & 1][g] = *(const bf16x8*)(smem + RST * IMG_BYTES + g * 4096 + lofsA[RKS]);             \
+        fr[RKS & 1][4 + g] = *(const bf16x8*)(smem + RST * IMG_BYTES + g * 4096 + lofsB[RKS]);         \
+      }                                                                                                \
+      if (!(VAR & 4) && !(VAR & 16)) write_piece(WST, Q0 + g, stg[KS][g]);                             \
+      if (!(VAR & 4) && !(VAR & 32)) load_piece(Q0 + g, stg[KS][g]);                                   \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
+        /* swapped operands: D[n][m] - a lane holds one output row m and groups of 4 consecutive columns */ \
+        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(KS) & 1][4 + j], fr[(KS) & 1][g],        \
+                                                            (FIRST) ? fzero : acc[g][j], 0, 0, 0);       \
+      }                                                                                                \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* MFMA */                                    \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* DS read */                                 \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); /* DS write */                                \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); /* the buffer load (a VMEM read) */           \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+    }                                                                                                  \
+    if (VAR & 16) { _Pragma("unroll") for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(stg[KS][g])); } \
+    if ((KS) == 2) {                                                                                   \
+      advance_prefetch();                                                                              \
+      wait_lgkm0();                                                                                    \
+      if (!(VAR & 1)) barrier();                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+    }                                                                                                  \
   } while (0)
+#define STONK_W4_KTILE(ST, FIRST)    \
+  do {                               \
+    STONK_W4_KSTEP(ST, 0, FIRST);    \
+    STONK_W4_KSTEP(ST, 1, false);    \
+    STONK_W4_KSTEP(ST, 2, false);    \
+    STONK_W4_KSTEP(ST, 3, false);    \
+  } while (0)
+
+  // ---- prologue (not pipelined): K tile 0 complete in stage 0, pieces 0-3 of K tile 1 in stage 1, the rest of K tile 1
+  // and pieces 0-3 of K tile 2 requested into the staging registers, first fragments read
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_piece(4 * g + i, stg[g][i]);
+  advance_prefetch();
+  wait_vm<0>();
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) write_piece(0, 4 * g + i, stg[g][i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_piece(i, stg[3][i]);
+  wait_vm<0>();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) write_piece(1, i, stg[3][i]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_piece(4 * (g + 1) + i, stg[g][i]);
+  advance_prefetch();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_piece(i, stg[3][i]);
+  wait_lgkm0();
+  barrier();
+  read_frags(0, 0, fr[0]);
+  __builtin_amdgcn_sched_barrier(0);
 
   // ---- epilogue: a wave drains its 128x128 corner in 8 rounds of 32 rows x 64 columns through a private 8 KiB slab
   // (XOR-swizzled), so that every global access - output, residual, saved pre-activation - is a 16-byte-per-lane row
-  // segment (8 lanes = one 128-byte line of bf16).
+  // segment (8 lanes = one 128-byte line of bf16). All of them are BUFFER accesses: a per-lane offset that does not
+  // depend on the round (row-in-group * ld + column * size) + the round's uniform offset, one v_add - no 64-bit address
+  // arithmetic, few registers (what the K loop keeps live across the epilogue is not spilled), and rows past M fall off
+  // the end of the buffer instead of needing a predicate.
+  // The uniform part is ADDED INTO the vector offset rather than passed as the instruction's scalar offset: a
+  // buffer_store_dwordx4 with an SGPR offset reads its last data dwords late, and a following VALU write to those
+  // registers (the next round's values) reached memory instead - seen here as the last 8 bytes of the round's last
+  // store in the upper lanes carrying the NEXT round's data (the classic >64-bit-store data hazard; the toolchain does
+  // not pad it on this target).
+  typedef __attribute__((ext_vector_type(4))) unsigned eu32x4;
   auto store_tile = [&](const Work& w) {
-    char* ep = smem + LDS_RING + wave * SLAB_BYTES;
+    // the lane id is re-read from the hardware and the wave id made opaque: the epilogue's addresses are derived HERE,
+    // not hoisted out of the K loop (where they would be spilled and reloaded behind a compiler-placed vmcnt(0))
+    int lv = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), wv = wave;
+    asm volatile("" : "+v"(lv), "+s"(wv));
+    const int r = lv & 31, hh = lv >> 5;
+    char* ep = smem + LDS_RING + wv * SLAB_BYTES;
     const int flags = EPI >= 0 ? EPI : p.flags;
-    const int rrow = lane >> 3, c8 = lane & 7;
+    const int rrow = lv >> 3, c8 = lv & 7;
+    const int esz = OUT_MODE == 0 ? 2 : 4;
+    const int ldc_b = (int)p.ldc * esz, ldr_b = (int)p.ldr * 2, ldx_b = (int)p.ldaux * 2;
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, M * ldc_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, M * ldr_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.aux, 0, M * ldx_b, 0x00020000);
+    const int wm0 = w.m0 + (wv >> 1) * 128, wn0 = w.n0 + (wv & 1) * 128;
 #pragma unroll
-    for (int qa = 0; qa < 2; ++qa)
+    for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
-      for (int bi = 0; bi < 2; ++bi)
+      for (int qb = 0; qb < 2; ++qb) {
+        const int mrow0 = wm0 + bi * 32;
+        const int n0 = wn0 + qb * 64;
+        const int n = n0 + c8 * 8;
+        const bool n_ok = n < N;
+        const int oob = n_ok ? 0 : 0x40000000;   // columns past N: pushed out of the buffer's range
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        if ((flags & STONK_EPI_BIAS) && n_ok) {
+          b0 = *(const f32x4*)(p.bias + n);
+          b1 = *(const f32x4*)(p.bias + n + 4);
+        }
+        // write: lane holds row r, register group g -> columns 8g + 4hh .. +3 of each 32-column block
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-          const int mrow0 = w.m0 + wr * 128 + qa * 64 + bi * 32;
-          const int n0 = w.n0 + wc * 128 + qb * 64;
-          const int n = n0 + c8 * 8;
-          const bool n_ok = n < N;
-          f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-          if ((flags & STONK_EPI_BIAS) && n_ok) {
-            b0 = *(const f32x4*)(p.bias + n);
-            b1 = *(const f32x4*)(p.bias + n + 4);
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int ch = bj * 8 + 2 * g + hh;   // 16-byte chunk of the 256-byte slab row
+            const f32x16& c = acc[bi][2 * qb + bj];
+            f32x4 v = {c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+            *(f32x4*)(ep + r * 256 + ((ch ^ (r & 15)) << 4)) = v * p.alpha;
           }
-          // write: lane holds row r, register group g -> columns 8g + 4hh .. +3 of each 32-column block
-#pragma unroll
-          for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int ch = bj * 8 + 2 * g + hh;   // 16-byte chunk of the 256-byte slab row
-              const f32x16& c = acc[qa][qb][bi][bj];
-              f32x4 v = {c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
-              *(f32x4*)(ep + r * 256 + ((ch ^ (r & 15)) << 4)) = v * p.alpha;
-            }
-          __builtin_amdgcn_wave_barrier();
-          if (OUT_MODE == 2) {
-            // fp32 accumulate: one atomic wave-instruction = 64 consecutive floats of one row
+        __builtin_amdgcn_wave_barrier();
+        if (OUT_MODE == 2) {
+          // fp32 accumulate: one atomic wave-instruction = 64 consecutive floats of one row
 #pragma unroll 4
-            for (int rr = 0; rr < 32; ++rr) {
-              const float x = *(const float*)(ep + rr * 256 + (((lane >> 2) ^ (rr & 15)) << 4) + (lane & 3) * 4);
-              if (mrow0 + rr < M && n0 + lane < N) atomicAdd((float*)p.C + (long)(mrow0 + rr) * p.ldc + n0 + lane, x);
-            }
-          } else {
+          for (int rr = 0; rr < 32; ++rr) {
+            const float x = *(const float*)(ep + rr * 256 + (((lv >> 2) ^ (rr & 15)) << 4) + (lv & 3) * 4);
+            if (mrow0 + rr < M && n0 + lv < N) atomicAdd((float*)p.C + (long)(mrow0 + rr) * p.ldc + n0 + lv, x);
+          }
+        } else {
+          const int voC = rrow * ldc_b + c8 * 8 * esz + oob;
+          const int voR = rrow * ldr_b + c8 * 16 + oob, voX = rrow * ldx_b + c8 * 16 + oob;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-              const int row = it * 8 + rrow;
-              const int mm = mrow0 + row;
-              const f32x4 q0 = *(const f32x4*)(ep + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
-              const f32x4 q1 = *(const f32x4*)(ep + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
-              if (mm < M && n_ok) {
-                float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-                SideOps so;
-                side_prefetch(so, p, flags, mm, n, true);
-                epilogue8_pre(v, p, flags, mm, n, b0, b1, so);
-                if (OUT_MODE == 0) {
-                  bf16x8 o;
+          for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + rrow;
+            const int mm = mrow0 + row;
+            const int mrow = mrow0 + it * 8;   // uniform part of the row
+            const f32x4 q0 = *(const f32x4*)(ep + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
+            const f32x4 q1 = *(const f32x4*)(ep + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
+            float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+            SideOps so;
+            if (flags & STONK_EPI_GELU_BWD)
+              so.aux = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rX, voX + mrow * ldx_b + n0 * 2, 0, 0));
+            if (flags & STONK_EPI_RESID)
+              so.res = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rR, voR + mrow * ldr_b + n0 * 2, 0, 0));
+            // (bias, GELU, GELU', dropout, residual on the 8 values; the saved pre-activation leaves from here as well)
+            if (flags & STONK_EPI_BIAS) {
 #pragma unroll
-                  for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-                  *(bf16x8*)((bf16*)p.C + (long)mm * p.ldc + n) = o;
-                } else {
-                  float* dst = (float*)p.C + (long)mm * p.ldc + n;
-                  *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
-                  *(f32x4*)(dst + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                }
+              for (int e = 0; e < 4; ++e) {
+                v[e] += b0[e];
+                v[4 + e] += b1[e];
               }
             }
+            if (flags & STONK_EPI_SAVE_PREACT) {
+              bf16x8 u;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) u[e] = (bf16)v[e];
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(eu32x4, u), rX, voX + mrow * ldx_b + n0 * 2, 0, 0);
+            }
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            epilogue8_pre(v, p, flags & ~(STONK_EPI_BIAS | STONK_EPI_SAVE_PREACT), mm, n, z4, z4, so);
+            if (OUT_MODE == 0) {
+              bf16x8 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(eu32x4, o), rC, voC + mrow * ldc_b + n0 * 2, 0, 0);
+            } else {
+              const eu32x4 lo = __builtin_bit_cast(eu32x4, (f32x4){v[0], v[1], v[2], v[3]});
+              const eu32x4 hi = __builtin_bit_cast(eu32x4, (f32x4){v[4], v[5], v[6], v[7]});
+              __builtin_amdgcn_raw_buffer_store_b128(lo, rC, voC + mrow * ldc_b + n0 * 4, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(hi, rC, voC + mrow * ldc_b + n0 * 4 + 16, 0, 0);
+            }
           }
-          __builtin_amdgcn_wave_barrier();
         }
+        __builtin_amdgcn_wave_barrier();
+      }
   };
 
   // ------------------------------------------------------------------ stream of K tiles
-  int mode = 0;   // 1: the next two K tiles follow a full-tile boundary (their first six phases count its stores)
-  for (;;) {   // one output tile (work item) per iteration; the DMA stream runs across iterations
-    zero_acc();
-    for (int ck = 0; ck < cw.nk; ck += 2) {   // (the launcher guarantees an even number of K tiles per work item)
-      {
-        const bool post01 = mode != 0, post23 = mode != 0;
-        STONK_W4_KTILE(0);
-      }
-      {
-        const bool post01 = mode != 0, post23 = false;
-        STONK_W4_KTILE(1);
-      }
-      mode = 0;
+  int mode = 0;   // 1: the next K tile follows a full-tile boundary (its waits count the boundary's stores)
+  for (;;) {   // one output tile (work item) per iteration; the load stream runs across iterations
+    {   // the first pair of K tiles: accumulators start from zero; after a full-tile boundary the first K tile's waits
+        // count the boundary's stores
+      const bool post = mode != 0;
+      STONK_W4_KTILE(0, true);
+    }
+    {
+      const bool post = false;
+      STONK_W4_KTILE(1, false);
+    }
+    for (int ck = 2; ck < cw.nk; ck += 2) {   // (the launcher guarantees an even number of K tiles per work item)
+      const bool post = false;
+      STONK_W4_KTILE(0, false);
+      STONK_W4_KTILE(1, false);
     }
     store_tile(cw);
     // the store count the post-boundary waits assume is only exact for a tile without masked rows / columns
@@ -422,8 +444,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     if (!more) break;
     cw = nw;
   }
-  // the ring may still be receiving the cursor's last (unused) half-tiles: let them land before the LDS is released
-  wait_vm<0>();
+  wait_vm<0>();   // (the cursor's last, unused loads)
+#undef STONK_W4_KTILE
+#undef STONK_W4_KSTEP
 }
 
 template <int OUT_MODE, int EPI, int VAR = 0>
@@ -462,12 +485,12 @@ int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, hipStream_t st) {
       static const int var = getenv("STONK_W4_VAR") ? atoi(getenv("STONK_W4_VAR")) : 0;   // timing experiments
       switch (var) {
         case 1: return launch_w4<0, 0, 1>(a, grid, st);
-        case 2: return launch_w4<0, 0, 2>(a, grid, st);
-        case 3: return launch_w4<0, 0, 3>(a, grid, st);
         case 4: return launch_w4<0, 0, 4>(a, grid, st);
         case 8: return launch_w4<0, 0, 8>(a, grid, st);
         case 12: return launch_w4<0, 0, 12>(a, grid, st);
         case 13: return launch_w4<0, 0, 13>(a, grid, st);
+        case 16: return launch_w4<0, 0, 16>(a, grid, st);
+        case 32: return launch_w4<0, 0, 32>(a, grid, st);
         default: return launch_w4<0, 0>(a, grid, st);
       }
     }

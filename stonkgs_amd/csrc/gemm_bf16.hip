@@ -333,11 +333,24 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   // the four-wave kernel walks K tiles in pairs: an even number per work item
   // ... and addresses its operands with 32-bit byte offsets from a per-K-tile base, chunk-swizzled by XOR (ld % 64)
   const bool w4_ok = ldc % 8 == 0 && !both_sides && (K / BK) % (2 * split_k) == 0 && !k_dev && lda % 64 == 0 &&
-                     ldb % 64 == 0 && (long)M * lda < (1L << 30) && (long)N * ldb < (1L << 30) && (long)M * ldc < (1L << 28) &&
+                     ldb % 64 == 0 && (long)M * lda < (1L << 30) && (long)N * ldb < (1L << 30) && (long)M * ldc * (out_mode == 0 ? 2 : 4) < (1L << 31) &&
                      (!(flags & STONK_EPI_RESID) || (ldr % 8 == 0 && (uintptr_t)resid % 16 == 0)) &&
                      (!(flags & (STONK_EPI_SAVE_PREACT | STONK_EPI_GELU_BWD)) ||
                       (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0));
-  if (w4_ok && (flags & STONK_EPI_DEBUG_W4)) return stonk_gemm_w4_launch(a, out_mode, st);
+  // measured on MI355X (tools/bench_kernels.py): the four-wave kernel is the fastest of the three on every large launch
+  // of the step (QKV 127 us vs 148, FFN-up 155 vs 178, N = 768 outputs 50 / 143 vs 59 / 152)
+  // ... but not with an epilogue that READS a second [M,N] operand (residual, GELU' input): vmcnt retires in order, so
+  // each round's wait for its side loads also waits for the previous rounds' stores - with one workgroup per CU nothing
+  // hides that (in the step those launches ran 1.5-2x slower than on the 128x128 kernel, two workgroups per CU)
+  const bool w4_side = (flags & (STONK_EPI_RESID | STONK_EPI_GELU_BWD)) != 0;
+  const bool w4_big = (M >= 1024 || m_dev) && out_mode != STONK_EPI_OUT_F32_ATOMIC && !w4_side &&
+                      !(flags & (STONK_EPI_DEBUG_V1 | STONK_EPI_DEBUG_V2 | STONK_EPI_DEBUG_REGSTAGE | STONK_EPI_DEBUG_SIDE_V1));
+  // ... yet the STEP is not faster with it (interleaved A/B, tools/ab_step.py: 42.75 ms against 42.45 with the weight
+  // gradients overlapping on the second stream, 43.2 against 43.8 without the overlap): what it gains on its own
+  // launches it takes from the overlapped weight-gradient kernels. Opt-in (STONK_W4=1 or the debug flag) until the
+  // weight gradients run on the same schedule.
+  static const bool use_w4 = getenv("STONK_W4") != nullptr;
+  if (w4_ok && ((w4_big && use_w4) || (flags & STONK_EPI_DEBUG_W4))) return stonk_gemm_w4_launch(a, out_mode, st);
   if (v2_ok && !(flags & (STONK_EPI_DEBUG_V1 | STONK_EPI_DEBUG_REGSTAGE)) && (big || (flags & STONK_EPI_DEBUG_V2)))
     return stonk_gemm256_launch(a, out_mode, st);
   const long tiles = (long)((M + BM - 1) / BM) * (N / BN) * split_k;

@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   // store in the upper lanes carrying the NEXT round's data (the classic >64-bit-store data hazard; the toolchain does
   // not pad it on this target).
   typedef __attribute__((ext_vector_type(4))) unsigned eu32x4;
+  f32x4 bq[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
   auto store_tile = [&](const Work& w) {
     // the lane id is re-read from the hardware and the wave id made opaque: the epilogue's addresses are derived HERE,
     // not hoisted out of the K loop (where they would be spilled and reloaded behind a compiler-placed vmcnt(0))
@@ -343,11 +344,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
         const int n = n0 + c8 * 8;
         const bool n_ok = n < N;
         const int oob = n_ok ? 0 : 0x40000000;   // columns past N: pushed out of the buffer's range
-        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-        if ((flags & STONK_EPI_BIAS) && n_ok) {
-          b0 = *(const f32x4*)(p.bias + n);
-          b1 = *(const f32x4*)(p.bias + n + 4);
-        }
+        const f32x4 b0 = bq[qb][0], b1 = bq[qb][1];
         // write: lane holds row r, register group g -> columns 8g + 4hh .. +3 of each 32-column block
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj)
@@ -418,6 +415,21 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   // ------------------------------------------------------------------ stream of K tiles
   int mode = 0;   // 1: the next K tile follows a full-tile boundary (its waits count the boundary's stores)
   for (;;) {   // one output tile (work item) per iteration; the load stream runs across iterations
+    // The bias of this lane's 2 x 8 output columns is requested HERE, a whole K loop before the epilogue uses it: a
+    // load issued in the epilogue would be waited for on the spot (draining the in-flight operand loads with it), and a
+    // load issued after the tile's first store could not complete, as far as vmcnt can tell, before that store retires.
+    // Buffer loads: columns past N read as zero, no branch.
+    if ((EPI >= 0 ? EPI : p.flags) & STONK_EPI_BIAS) {
+      const int lv = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, N * 4, 0x00020000);
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int n = cw.n0 + wc * 128 + qb * 64 + (lv & 7) * 8 + h * 4;
+          bq[qb][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBias, n * 4, 0, 0));
+        }
+    }
     {   // the first pair of K tiles: accumulators start from zero; after a full-tile boundary the first K tile's waits
         // count the boundary's stores
       const bool post = mode != 0;

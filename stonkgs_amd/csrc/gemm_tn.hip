@@ -15,10 +15,13 @@
 // Tile 128x128 over 64-token K steps, 4 waves (2x2), 2 workgroups per CU, LDS-DMA double buffered as gemm_bf16.hip.
 // LDS image: 256-byte rows (128 features), 16-byte chunk c of row r stored at c ^ (((r&3)<<2) | ((r>>2)&3))
 // (conflict-free for the transposed reads); the swizzle is applied on the DMA source address.
+#include <cstdlib>
+
 #include "gemm_common.h"
 
 // persistent 256x256 variant (gemm256.hip, TN = true)
 int stonk_gemm256_tn_launch(const stonk_gemm::GemmArgs& a, hipStream_t st);
+int stonk_gemm_tn_w4_launch(const stonk_gemm::GemmArgs& a, hipStream_t st);
 
 namespace {
 
@@ -187,24 +190,23 @@ extern "C" int stonk_gemm_tn_bf16(const void* dY, int64_t lda, const void* X, in
                                   void* stream) {
   STONK_CHECK_ARG(dY && X && dW, STONK_EINVAL);
   STONK_CHECK_ARG(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0, STONK_ESHAPE);
-  STONK_CHECK_ARG(split_k >= 0, STONK_ESHAPE);
+  STONK_CHECK_ARG(split_k >= -1, STONK_ESHAPE);
   STONK_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0, STONK_EALIGN);
   STONK_CHECK_ARG((uintptr_t)dY % 16 == 0 && (uintptr_t)X % 16 == 0, STONK_EALIGN);
-  // split_k == 0 selects the persistent 256x256 kernel (gemm256.hip, TN form) with an automatic split. Measured on
-  // MI355X (tools/sweep_wgrad.py) it only TIES the 128x128 kernel on this model's weights (760 vs 740-780 TFLOP/s on
-  // 3072x768, slower on 768x768), so the step keeps the 128x128 kernel with a tuned split; the variant stays for wider
-  // models.
-  if (split_k == 0) {
+  // split_k == 0 selects the four-wave 256x256 kernel (gemm_tn_w4.hip) with an automatic split: work items = tiles x
+  // splits aimed at one full round of the CUs. (split_k == -1 keeps the older eight-wave 256x256 TN form of gemm256.hip.)
+  if (split_k <= 0) {
     STONK_CHECK_ARG(M >= 256 && N >= 256, STONK_ESHAPE);
+    STONK_CHECK_ARG(lda % 64 == 0 && ldb % 64 == 0 && (long)K * lda < (1L << 30) && (long)K * ldb < (1L << 30), STONK_ESHAPE);
     stonk_gemm::GemmArgs g = {};
     g.A = (const bf16*)dY; g.B = (const bf16*)X; g.C = dW; g.bias = dbias; g.k_dev = k_dev;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha;
     const int nk = (K + BK - 1) / BK;
-    // work items = 256x256 tiles x splits: aim at one full round of the 256 CUs, at least 8 K tiles per item
     const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
     long sk = tiles >= 256 ? 1 : 256 / tiles;   // floor: tiles x splits must not spill into a second, mostly empty round
     if (sk > nk / 8) sk = nk / 8 > 0 ? nk / 8 : 1;
     g.split_k = (int)sk;
+    if (split_k == 0) return stonk_gemm_tn_w4_launch(g, (hipStream_t)stream);
     return stonk_gemm256_tn_launch(g, (hipStream_t)stream);
   }
   TnArgs a;

@@ -11,6 +11,7 @@ B=64 needs ~12 GB), nothing is recomputed except attention probabilities.
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -118,6 +119,11 @@ class Engine:
         # 128x128 tiles, two workgroups co-resident per CU = 512 slots on 256 CUs: the sweep in tools/sweep_wgrad.py
         # is fastest when tiles x split fills ONE co-resident wave without a tail (432-480 workgroups)
         tiles = ((M + 127) // 128) * (N // 128)
+        # the large weight gradients (FFN up / down, fused QKV) go to the four-wave 256x256 kernel, which splits K itself
+        # (split_k = 0): -1.4 ms per step in an interleaved A/B; 768 x 768 (36 tiles) and the label-sparse decoder
+        # gradients (device-side token counts, wide strides) stay on the 128x128 kernel
+        if tiles >= 100 and K >= 16384 and M % 256 == 0 and N % 256 == 0 and M <= 4096 and not os.environ.get("STONK_TN_V1"):
+            return 0
         return max(1, min(32, 480 // tiles, K // 64))
 
     def wgrad(self, dy, x, dW, db, M_out, N_in, T, k_dev=None, alpha=1.0):

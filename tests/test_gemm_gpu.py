@@ -206,8 +206,8 @@ def test_gemm_tn_asymmetric_and_device_token_count(hip):
 
 
 def test_gemm_tn_256_exact_and_matches_small_kernel(hip):
-    """The persistent 256x256 weight-gradient kernel: exact integer data (any fragment / swizzle / half-tile mix-up
-    shows), bias sums through the selector MFMA, agreement with the 128x128 kernel, bitwise-stable repeats."""
+    """The four-wave 256x256 weight-gradient kernel (split_k = 0): exact integer data (any fragment / sub-tile mix-up
+    shows), bias sums, agreement with the 128x128 kernel and the eight-wave form (split_k = -1)."""
     T, Mo, No = 2048, 768, 1024
     dY = torch.zeros(T, Mo, device="cuda", dtype=torch.bfloat16)
     dY[torch.arange(T), (torch.arange(T) * 7) % Mo] = 1.0
@@ -224,7 +224,7 @@ def test_gemm_tn_256_exact_and_matches_small_kernel(hip):
     dY, X = _rand((T, Mo), 0.5, 41), _rand((T, No), 0.5, 42)
     ref = dY.float().t() @ X.float()
     outs = []
-    for sk in (0, 4):
+    for sk in (0, -1, 4):
         dW = torch.zeros(Mo, No, device="cuda")
         db = torch.zeros(Mo, device="cuda")
         hip.call("stonk_gemm_tn_bf16", hip.ptr(dY), Mo, hip.ptr(X), No, hip.ptr(dW), No, hip.ptr(db), Mo, No, T, 1.0, sk,
@@ -243,3 +243,10 @@ def test_gemm_tn_256_exact_and_matches_small_kernel(hip):
     hip.call("stonk_gemm_tn_bf16", hip.ptr(dY), Mo, hip.ptr(X), No, hip.ptr(dW), No, 0, Mo, No, T, 1.0, 0,
              hip.ptr(k_dev), hip.stream_ptr())
     torch.testing.assert_close(dW, dY[:k].float().t() @ X[:k].float(), rtol=1e-4, atol=4e-3)
+    # the four-wave kernel range-checks tokens itself: rows past the device-side count may hold anything
+    dY[k:] = 1000.0
+    X[k:] = -1000.0
+    dW2 = torch.zeros(Mo, No, device="cuda")
+    hip.call("stonk_gemm_tn_bf16", hip.ptr(dY), Mo, hip.ptr(X), No, hip.ptr(dW2), No, 0, Mo, No, T, 1.0, 0,
+             hip.ptr(k_dev), hip.stream_ptr())
+    torch.testing.assert_close(dW2, dW, rtol=1e-5, atol=1e-4)

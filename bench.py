@@ -143,26 +143,27 @@ def main():
     roofline = None
     gemm_all = None
     if not args.no_roofline and rank == 0:
-        # dominant kernel of the step = gemm_tn_kernel (weight + bias gradients of every nn.Linear, 51 launches/step;
-        # profiles/ has the rocprofv3 kernel-trace of the same command): per-launch HIP events on the launch stream
-        # over two extra steps; achieved = algorithmic FLOPs (2 * M' * N' * tokens per launch) / summed durations
+        # dominant kernel of the step = gemm_tn_w4_kernel (weight + bias gradients of the FFN and fused-QKV linears, 36
+        # launches/step; profiles/ has the rocprofv3 kernel-trace of the same command): per-launch HIP events on the
+        # launch stream over two extra steps; achieved = algorithmic FLOPs (2 * M' * N' * tokens per launch) / summed
+        # durations
         from stonkgs_amd.engine import GemmTimer
 
         model.engine.gemm_timer = GemmTimer()
         for i in range(2):
             trainer.training_step(model, batches[i % len(batches)])
-        s = model.engine.gemm_timer.summarize("tn")
+        s = model.engine.gemm_timer.summarize("tn_w4")
         a = model.engine.gemm_timer.summarize(None)
         model.engine.gemm_timer = None
         ach = s["flops"] / s["seconds"] / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_tn_kernel (bf16 MFMA 16x16x32, 128x128 tiles over 64-token steps, "
-                                               "transposed LDS reads, split-K fp32 atomics)",
+        roofline = {"bound": "mfma", "kernel": "gemm_tn_w4_kernel (bf16 MFMA 32x32x16, 256x256 tiles over 64-token steps, four "
+                                               "waves, transposed LDS reads, split-K fp32 atomics)",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": s["launches"] // 2,
                     "avg_launch_us": round(s["seconds"] / s["launches"] * 1e6, 1),
                     "avg_launch_gflop": round(s["flops"] / s["launches"] / 1e9, 2)}
-        gemm_all = {"kernels": "gemm_tn_kernel + gemm_nt_kernel + gemm256_kernel", "launches_per_step": a["launches"] // 2,
+        gemm_all = {"kernels": "gemm_tn_w4_kernel + gemm_tn_kernel + gemm_nt_kernel + gemm256_kernel", "launches_per_step": a["launches"] // 2,
                     "achieved_tflops": round(a["flops"] / a["seconds"] / 1e12, 1),
                     "frac": round(a["flops"] / a["seconds"] / 1e12 / PEAK_BF16_TFLOPS, 4),
                     "ms_per_step": round(a["seconds"] / 2 * 1e3, 2)}

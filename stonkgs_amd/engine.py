@@ -35,7 +35,8 @@ class GemmTimer:
 
     def summarize(self, kind=None):
         """Algorithmic FLOPs use the rows / contraction length that exist at run time (device-side counts of the
-        label-sparse decoders), not the launch capacity. kind: "tn" (weight-gradient kernel), "nt", or None = all."""
+        label-sparse decoders), not the launch capacity. kind: "tn_w4" / "tn" (weight-gradient kernels: four-wave 256x256 /
+        128x128), "nt", or None = all."""
         torch.cuda.synchronize()
         tot_t = tot_f = 0.0
         n = 0
@@ -148,7 +149,8 @@ class Engine:
                  hip.stream_ptr())
         if timed:
             e1.record()
-            self.gemm_timer.records.append(("tn", e0, e1, M_out, N_in, T, None, k_dev))
+            kind = "tn_w4" if self._split_k(M_out, N_in, T) == 0 else "tn"
+            self.gemm_timer.records.append((kind, e0, e1, M_out, N_in, T, None, k_dev))
 
     def transpose(self, x, rows, cols, name, colsum=None, rows_dev=None):
         rpad = (rows + 63) // 64 * 64

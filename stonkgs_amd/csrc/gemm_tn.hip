@@ -190,23 +190,28 @@ extern "C" int stonk_gemm_tn_bf16(const void* dY, int64_t lda, const void* X, in
                                   void* stream) {
   STONK_CHECK_ARG(dY && X && dW, STONK_EINVAL);
   STONK_CHECK_ARG(M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0, STONK_ESHAPE);
-  STONK_CHECK_ARG(split_k >= -1, STONK_ESHAPE);
   STONK_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0, STONK_EALIGN);
   STONK_CHECK_ARG((uintptr_t)dY % 16 == 0 && (uintptr_t)X % 16 == 0, STONK_EALIGN);
   // split_k == 0 selects the four-wave 256x256 kernel (gemm_tn_w4.hip) with an automatic split: work items = tiles x
-  // splits aimed at one full round of the CUs. (split_k == -1 keeps the older eight-wave 256x256 TN form of gemm256.hip.)
+  // splits aimed at one full round of the CUs. split_k <= -16: the same kernel limited to -split_k CUs' worth of
+  // workgroups - for launches that run on a second stream beside other work: a persistent one-workgroup-per-CU kernel that
+  // takes every CU stalls the other stream until its workgroups retire (the step is 1.5 ms faster with the weight
+  // gradients on 160 of the 256 CUs). split_k == -1 keeps the older eight-wave 256x256 TN form of gemm256.hip.
   if (split_k <= 0) {
     STONK_CHECK_ARG(M >= 256 && N >= 256, STONK_ESHAPE);
     STONK_CHECK_ARG(lda % 64 == 0 && ldb % 64 == 0 && (long)K * lda < (1L << 30) && (long)K * ldb < (1L << 30), STONK_ESHAPE);
+    STONK_CHECK_ARG(split_k >= -1024, STONK_ESHAPE);
     stonk_gemm::GemmArgs g = {};
     g.A = (const bf16*)dY; g.B = (const bf16*)X; g.C = dW; g.bias = dbias; g.k_dev = k_dev;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha;
     const int nk = (K + BK - 1) / BK;
     const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
-    long sk = tiles >= 256 ? 1 : 256 / tiles;   // floor: tiles x splits must not spill into a second, mostly empty round
+    const long cus = split_k <= -16 ? -split_k : 256;
+    long sk = tiles >= cus ? 1 : cus / tiles;   // floor: tiles x splits must not spill into a second, mostly empty round
     if (sk > nk / 8) sk = nk / 8 > 0 ? nk / 8 : 1;
     g.split_k = (int)sk;
-    if (split_k == 0) return stonk_gemm_tn_w4_launch(g, (hipStream_t)stream);
+    g.flags = (int)cus;   // grid cap
+    if (split_k != -1) return stonk_gemm_tn_w4_launch(g, (hipStream_t)stream);
     return stonk_gemm256_tn_launch(g, (hipStream_t)stream);
   }
   TnArgs a;

@@ -387,7 +387,8 @@ int stonk_gemm_tn_w4_launch(const GemmArgs& a, hipStream_t st) {
     attr_done = true;
   }
   const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.split_k;
-  const int grid = (int)(tiles < n_cu ? tiles : n_cu);
+  const int cap = (a.flags > 0 && a.flags < n_cu) ? a.flags : n_cu;
+  const int grid = (int)(tiles < cap ? tiles : cap);
   hipLaunchKernelGGL(gemm_tn_w4_kernel, dim3(grid), dim3(256), LDS_BYTES, st, a);
   return stonk_launch_status();
 }

@@ -116,15 +116,16 @@ class Engine:
             self.gemm_timer.records.append(("nt", e0, e1, M, N, K, m_dev, k_dev))
 
     @staticmethod
-    def _split_k(M, N, K) -> int:
+    def _split_k(M, N, K, side_stream=False) -> int:
         # 128x128 tiles, two workgroups co-resident per CU = 512 slots on 256 CUs: the sweep in tools/sweep_wgrad.py
         # is fastest when tiles x split fills ONE co-resident wave without a tail (432-480 workgroups)
         tiles = ((M + 127) // 128) * (N // 128)
         # the large weight gradients (FFN up / down, fused QKV) go to the four-wave 256x256 kernel, which splits K itself
         # (split_k = 0): -1.4 ms per step in an interleaved A/B; 768 x 768 (36 tiles) and the label-sparse decoder
-        # gradients (device-side token counts, wide strides) stay on the 128x128 kernel
+        # gradients (device-side token counts, wide strides) stay on the 128x128 kernel. Beside the dgrad chain (second
+        # stream) the kernel is held to 160 CUs' worth of workgroups (split_k = -160): another -1.5 ms
         if tiles >= 100 and K >= 16384 and M % 256 == 0 and N % 256 == 0 and M <= 4096 and not os.environ.get("STONK_TN_V1"):
-            return 0
+            return -int(os.environ.get("STONK_TN_CUS", "160")) if side_stream else 0
         return max(1, min(32, 480 // tiles, K // 64))
 
     def wgrad(self, dy, x, dW, db, M_out, N_in, T, k_dev=None, alpha=1.0):
@@ -137,8 +138,8 @@ class Engine:
             self._wstream.wait_event(ready)
             with torch.cuda.stream(self._wstream):
                 hip.call("stonk_gemm_tn_bf16", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(),
-                         dW.stride(0), hip.ptr(db), M_out, N_in, T, alpha, self._split_k(M_out, N_in, T), hip.ptr(k_dev),
-                         hip.stream_ptr())
+                         dW.stride(0), hip.ptr(db), M_out, N_in, T, alpha, self._split_k(M_out, N_in, T, True),
+                         hip.ptr(k_dev), hip.stream_ptr())
             return
         timed = self.gemm_timer is not None
         if timed:

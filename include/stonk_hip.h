@@ -43,8 +43,11 @@ int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, v
 
 /* Weight / bias gradient straight from row-major activations: dW[M',N'] += alpha * dY[T,M']^T . X[T,N'],
  * db[M'] += alpha * colsum(dY) (nullable). M', N' % 128 == 0; rows of dY / X in [k, roundup64(k)) must read as zero when
- * the token count k (<= K) comes from k_dev. split_k >= 1: 128x128 tiles with that many K splits; split_k == 0: the
- * persistent 256x256 kernel with an automatic split. Autograd's weight/bias gradients of every nn.Linear on the path. */
+ * the token count k (<= K) comes from k_dev (the 256x256 kernels range-check tokens themselves). split_k >= 1: 128x128
+ * tiles with that many K splits; split_k == 0: the four-wave 256x256 kernel (M', N' >= 256, lda / ldb % 64 == 0) with an
+ * automatic split over all CUs; split_k <= -16: the same kernel held to -split_k CUs' worth of workgroups (launches on
+ * a second stream beside other work); split_k == -1: the older eight-wave 256x256 form.
+ * Autograd's weight/bias gradients of every nn.Linear on the path. */
 int stonk_gemm_tn_bf16(const void* dY, int64_t lda, const void* X, int64_t ldb, float* dW, int64_t ldc, float* dbias,
                        int M, int N, int K, float alpha, int split_k, const int* k_dev, void* stream);
 

@@ -71,6 +71,11 @@ class Engine:
         # Weight-gradient GEMMs are off the critical path of backward (nothing downstream reads dW until the optimizer):
         # they are launched on a second HIP stream and overlap the dgrad / LayerNorm / attention chain on the main one.
         self.overlap_wgrad = True
+        # Set by the trainer when gradients are all-reduced while backward runs (world size > 1): RCCL's kernels then hold
+        # some CUs for the length of a collective, and a PERSISTENT one-workgroup-per-CU kernel with a static tile split
+        # would wait for them (its late workgroups own a share of the tiles). Backward's only such launch on the main
+        # stream (dgrad through GELU) then takes the 128x128 kernel, whose grid the hardware schedules dynamically.
+        self.comm_overlap = False
         self._wstream: Optional[torch.cuda.Stream] = None
         self._wgrad_done: Dict[int, torch.cuda.Event] = {}   # layer parity -> side-stream event after its last wgrad
 
@@ -256,7 +261,8 @@ class Engine:
         # ---- FFN down: wgrad, bias grad, dgrad fused with GELU'
         self.wgrad(df, sv["g"], g_(prefix + ".output.dense.weight"), g_(prefix + ".output.dense.bias"), H, I, T)
         du = self.buf(f"b.du.{par}", (T, I))
-        self.gemm(df, wt[prefix + ".output.dense.weight"], du, T, I, H, flags=hip.EPI_GELU_BWD, aux=sv["u"])
+        self.gemm(df, wt[prefix + ".output.dense.weight"], du, T, I, H,
+                  flags=hip.EPI_GELU_BWD | (hip.EPI_DEBUG_V1 if self.comm_overlap else 0), aux=sv["u"])
         # ---- FFN up
         self.wgrad(du, sv["h1"], g_(prefix + ".intermediate.dense.weight"), g_(prefix + ".intermediate.dense.bias"), I, H,
                    T)

@@ -185,6 +185,7 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.sync = GradSynchronizer(model._store.grad, segment_ends_for(model), self.args.ddp_bucket_mb)
+        model.engine.comm_overlap = self.world > 1   # (see Engine.comm_overlap)
         self.global_step = 0
         self._micro = 0
         self.log_history: List[dict] = []

@@ -367,8 +367,9 @@ class Engine:
         pooled = self.buf("h.pooled", (B, H), F32)
         hip.call("stonk_small_linear_fwd", seq_out.data_ptr(), S * H, f("bert.pooler.dense.weight").data_ptr(),
                  f("bert.pooler.dense.bias").data_ptr(), pooled.data_ptr(), B, H, H, hip.SMALL_TANH, st)
-        save.update(B=B, attention_mask=attention_mask, token_type_ids=token_type_ids, sum0=sum0, st0=st0,
-                    seq_out=seq_out, pooled=pooled, p_hid=p_hid, p_att=p_att)
+        if save is not None:   # (None: forward-only callers - embedding extraction, batched inference)
+            save.update(B=B, attention_mask=attention_mask, token_type_ids=token_type_ids, sum0=sum0, st0=st0,
+                        seq_out=seq_out, pooled=pooled, p_hid=p_hid, p_att=p_att)
         return seq_out, pooled
 
     def forward(self, input_ids, attention_mask, token_type_ids, mlm_labels, ent_labels, nsp_labels, training: bool,

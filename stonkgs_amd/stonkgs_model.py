@@ -347,6 +347,32 @@ class STonKGsForPreTraining(nn.Module):
             hidden_states=out["hidden_states"].float(), attentions=None, pooler_output=out["pooler_output"].clone())
 
 
+    # -------------------------------------------------------------- forward-only encoder (embedding extraction)
+    @torch.no_grad()
+    def encode(self, input_ids, attention_mask=None, token_type_ids=None):
+        """(sequence_output bf16 [B, S, H], pooler_output fp32 [B, H]) without the pre-training heads: what
+        ``model(**row, return_dict=True).pooler_output`` costs in ref:stonkgs_for_embeddings.py:179 minus the two
+        vocabulary-wide decoders, whose logits that caller throws away. Dropout is off (the reference's
+        ``from_pretrained`` models are in eval mode); any batch size."""
+        cfg = self.config
+        dev = self._device
+
+        def prep(t):
+            if t is None:
+                return None
+            t = torch.as_tensor(t)
+            if t.device != dev or t.dtype != torch.long or not t.is_contiguous():
+                t = t.to(device=dev, dtype=torch.long).contiguous()
+            return t
+
+        input_ids, attention_mask, token_type_ids = prep(input_ids), prep(attention_mask), prep(token_type_ids)
+        if input_ids.dim() != 2 or input_ids.shape[1] != cfg.max_position_embeddings:
+            raise ValueError(f"input_ids must be [B, {cfg.max_position_embeddings}] (text half | entity half)")
+        seq_out, pooled = self.engine.encode(input_ids, attention_mask, token_type_ids, False, None)
+        self.engine.check_errors()
+        B = input_ids.shape[0]
+        return seq_out.view(B, cfg.max_position_embeddings, cfg.hidden_size).clone(), pooled.clone()
+
     # -------------------------------------------------------------- fused training path (no autograd)
     def forward_backward(self, inputs: Dict[str, torch.Tensor], gscale: float = 1.0, on_segment_done=None):
         """forward + hand-written backward in one call: what ``Trainer.training_step`` does through

@@ -112,3 +112,28 @@ def test_model_fails_loudly_without_gpu():
 
     with pytest.raises(_hip.StonkHipError):
         STonKGsForPreTraining(STonKGsConfig())
+
+
+def test_embedding_helper_batching_is_host_only_logic():
+    """Row collection / batching of stonkgs_for_embeddings (f2): DataFrame, list-of-dicts and dict-of-columns inputs,
+    ragged last batch, optional columns, index selection - no GPU needed."""
+    import pandas as pd
+
+    from stonkgs_amd.stonkgs_for_embeddings import _batches, _rows_of
+
+    rows = [{"input_ids": [i, i + 1, i + 2], "attention_mask": [1, 1, 0], "token_type_ids": [0, 0, 1], "extra": 7}
+            for i in range(5)]
+    df = pd.DataFrame(rows)
+    for data in (df, rows, {k: [r[k] for r in rows] for k in rows[0]}):
+        got = _rows_of(data, [4, 0])
+        assert [list(r["input_ids"]) for r in got] == [[4, 5, 6], [0, 1, 2]]
+    sizes = [b[0].shape[0] for b in _batches(_rows_of(df, None), 2)]
+    assert sizes == [2, 2, 1]
+    ids, am, tt = next(_batches(_rows_of(df, None), 4))
+    assert ids.dtype == torch.long and ids.tolist()[3] == [3, 4, 5] and am.tolist()[0] == [1, 1, 0] and tt is not None
+    ids, am, tt = next(_batches([{"input_ids": [1, 2]}], 8))
+    assert am is None and tt is None
+    with pytest.raises(KeyError):
+        next(_batches([{"attention_mask": [1]}], 1))
+    with pytest.raises(ValueError):
+        next(_batches(rows, 0))

@@ -107,6 +107,27 @@ int stonk_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_ou
 int stonk_transpose_f32_to_bf16(const float* in, void* out, int64_t rows, int cols, int64_t ld_out, void* stream);
 int stonk_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 
+/* On-device dynamic masking: ids_in [B,S] -> ids_out [B,S] + text / entity labels [B,half]. Per half,
+ * exactly k_* positions (the reference uses int(half * 0.15)) chosen uniformly without replacement - padding included,
+ * as the reference masks the padded sequence; 80 % -> mask_id, 10 % kept, 10 % uniform id in [0, vocab_*-1]; labels =
+ * original id there, -100 elsewhere. Counter-based random stream (seed, row, half, position), restated bit for bit by
+ * oracle/masking_oracle.py. Replaces ref:src/stonkgs/data/indra_for_pretraining.py:33-77 (replace_mlm_tokens), whose
+ * own Mersenne-Twister draws stay reproducible on the host path (stonkgs_amd/data.py). */
+int stonk_mlm_mask(const int64_t* ids_in, int64_t* ids_out, int64_t* text_labels, int64_t* ent_labels, int B, int S,
+                   int half, int64_t vocab_text, int64_t vocab_ent, int64_t mask_id, int k_text, int k_ent, uint32_t seed,
+                   void* stream);
+
+/* On-device row assembly: text_ids / text_attention [B,half] (already padded), source / target [B] node indices into
+ * walks [n_nodes, walk_len] (2 * walk_len + 2 == half) -> ids_out / attention_out / type_out [B,S], nsp_out [B]. Entity
+ * half = walks[source] [SEP] walks[target] [SEP]; with probability negative_rate a row takes the entity half of another
+ * row of the batch and NSP label 1 (the reference appends 25 % such rows offline: the same 1 in 5). A node index outside
+ * the table sets bit 0 of *err_flag (the reference raises KeyError). Replaces
+ * ref:src/stonkgs/data/indra_for_pretraining.py:190-239 (row assembly) and :80-126 (negative NSP samples). */
+int stonk_assemble_rows(const int64_t* text_ids, const int64_t* text_attention, const int64_t* source,
+                        const int64_t* target, const int64_t* walks, int64_t n_nodes, int walk_len, int64_t* ids_out,
+                        int64_t* attention_out, int64_t* type_out, int64_t* nsp_out, int B, int S, int half,
+                        int64_t sep_id, float negative_rate, uint32_t seed, int* err_flag, void* stream);
+
 /* Labelled-row compaction for the MLM / ELM heads (labels != -100), count kept on the device.
  * rows_out[i] = b*S + offset + pos of the i-th labelled position. Semantics of nn.CrossEntropyLoss(ignore_index
  * =-100) at ref:stonkgs_model.py:229-240. */

@@ -51,6 +51,9 @@ _SIGNATURES = {
     "stonk_transpose_bf16": [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp],
     "stonk_transpose_f32_to_bf16": [_vp, _vp, _i64, _i32, _i64, _vp],
     "stonk_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+    "stonk_mlm_mask": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _u32, _vp],
+    "stonk_assemble_rows": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _f32, _u32, _vp,
+                            _vp],
     "stonk_label_compact": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "stonk_gather_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _vp],
     "stonk_scatter_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp],

@@ -56,16 +56,18 @@ def add_negative_nsp_samples(rows: List[Dict[str, list]], nsp_negative_proportio
 
 def assemble_row(text_ids: Sequence[int], walk_source: Sequence[int], walk_target: Sequence[int], vocab_size: int,
                  kg_vocab_size: int, half: int = 256) -> Dict[str, list]:
-    """One positive pre-training row (ref:indra_for_pretraining.py:190-239): masked text half padded to `half`,
-    entity half = masked(source walk + [SEP] + target walk + [SEP]); NSP label 0."""
+    """One positive pre-training row (ref:indra_for_pretraining.py:190-239): the text ids are padded to `half` FIRST
+    (the tokenizer's padding="max_length") and the padded sequence is masked, so all `half` positions - padding
+    included - are candidates and every row carries int(half * 0.15) = 38 text labels, as in the reference; entity
+    half = masked(source walk + [SEP] + target walk + [SEP]); NSP label 0."""
     n = len(text_ids)
     assert n <= half and len(walk_source) + len(walk_target) + 2 == half
-    ent = list(walk_source) + [SEP_ID] + list(walk_target) + [SEP_ID]
-    t_in, t_lab = replace_mlm_tokens(list(text_ids), vocab_size)
-    e_in, e_lab = replace_mlm_tokens(ent, kg_vocab_size)
     pad = half - n
-    return {"input_ids": t_in + [PAD_ID] * pad + e_in, "attention_mask": [1] * n + [0] * pad + [1] * half,
-            "token_type_ids": [0] * half + [1] * half, "masked_lm_labels": t_lab + [-100] * pad,
+    ent = list(walk_source) + [SEP_ID] + list(walk_target) + [SEP_ID]
+    t_in, t_lab = replace_mlm_tokens(list(text_ids) + [PAD_ID] * pad, vocab_size)
+    e_in, e_lab = replace_mlm_tokens(ent, kg_vocab_size)
+    return {"input_ids": t_in + e_in, "attention_mask": [1] * n + [0] * pad + [1] * half,
+            "token_type_ids": [0] * half + [1] * half, "masked_lm_labels": t_lab,
             "ent_masked_lm_labels": e_lab, "next_sentence_labels": 0}
 
 
@@ -108,3 +110,73 @@ def example_batch(vocab_size: int = 28996, kg_vocab_size: int = 1000, seq_len: i
         rows.append(assemble_row(text, [int(x) for x in rng.randint(0, kg_vocab_size, w)],
                                  [int(x) for x in rng.randint(0, kg_vocab_size, w)], vocab_size, kg_vocab_size, half))
     return collate(rows)
+
+
+class DeviceBatcher:
+    """Per-step batch assembly and dynamic masking ON the device.
+
+    The reference tokenises, assembles and masks every row once, offline (ref:indra_for_pretraining.py:190-239, :33-77),
+    appends 25 % negative NSP rows (:80-126) and pickles the result (13.8 M rows); training then replays the same masks
+    every epoch. Here the static part stops at the tokenised text ids and the (source, target) node pair of each
+    statement; a step's ``input_ids`` / labels / NSP pairing are produced by two small kernels (csrc/data.hip) from a
+    counter-based random stream keyed by (seed, step), so every step sees fresh masks and fresh negatives. Same schema
+    and semantics as the reference's rows; the stream itself is restated bit for bit in oracle/masking_oracle.py.
+
+    ``walks``: int64 [n_nodes, half/2 - 1] - the random-walk node ids of every KG node (the reference's
+    ``random_walk_idx_dict``, a dict of lists, as one table)."""
+
+    def __init__(self, walks: torch.Tensor, vocab_size: int, kg_vocab_size: int, half: int = 256,
+                 nsp_negative_rate: float = 0.2, masked_tokens_percentage: float = 0.15, seed: int = 0,
+                 device="cuda:0"):
+        from . import _hip as hip
+
+        hip.lib()  # fail loudly without the extension / a GPU
+        self.hip = hip
+        self.device = torch.device(device)
+        self.walks = torch.as_tensor(walks).to(device=self.device, dtype=torch.long).contiguous()
+        if self.walks.dim() != 2 or 2 * self.walks.shape[1] + 2 != half:
+            raise ValueError(f"walks must be [n_nodes, {half // 2 - 1}]")
+        self.vocab_size, self.kg_vocab_size, self.half = int(vocab_size), int(kg_vocab_size), int(half)
+        self.k = int(half * masked_tokens_percentage)          # the reference's int(len * 0.15)
+        self.negative_rate, self.seed = float(nsp_negative_rate), int(seed)
+        self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def step_seed(self, step: int) -> int:
+        return (self.seed * 1000003 + int(step) * 7919 + 12345) & 0xFFFFFFFF
+
+    def __call__(self, text_ids, text_attention, source, target, step: int) -> Dict[str, torch.Tensor]:
+        hip, dev, half = self.hip, self.device, self.half
+
+        def prep(t):
+            return torch.as_tensor(t).to(device=dev, dtype=torch.long).contiguous()
+
+        text_ids, text_attention, source, target = prep(text_ids), prep(text_attention), prep(source), prep(target)
+        B = text_ids.shape[0]
+        if text_ids.shape != (B, half) or text_attention.shape != (B, half) or source.shape != (B,) or target.shape != (B,):
+            raise ValueError("text_ids / text_attention must be [B, half]; source / target [B]")
+        S = 2 * half
+        raw = torch.empty(B, S, dtype=torch.long, device=dev)
+        out = {"input_ids": torch.empty(B, S, dtype=torch.long, device=dev),
+               "attention_mask": torch.empty(B, S, dtype=torch.long, device=dev),
+               "token_type_ids": torch.empty(B, S, dtype=torch.long, device=dev),
+               "masked_lm_labels": torch.empty(B, half, dtype=torch.long, device=dev),
+               "ent_masked_lm_labels": torch.empty(B, half, dtype=torch.long, device=dev),
+               "next_sentence_labels": torch.empty(B, dtype=torch.long, device=dev)}
+        seed = self.step_seed(step)
+        st = hip.stream_ptr()
+        hip.call("stonk_assemble_rows", text_ids.data_ptr(), text_attention.data_ptr(), source.data_ptr(),
+                 target.data_ptr(), self.walks.data_ptr(), self.walks.shape[0], self.walks.shape[1], raw.data_ptr(),
+                 out["attention_mask"].data_ptr(), out["token_type_ids"].data_ptr(),
+                 out["next_sentence_labels"].data_ptr(), B, S, half, SEP_ID, self.negative_rate, seed,
+                 self.err.data_ptr(), st)
+        hip.call("stonk_mlm_mask", raw.data_ptr(), out["input_ids"].data_ptr(), out["masked_lm_labels"].data_ptr(),
+                 out["ent_masked_lm_labels"].data_ptr(), B, S, half, self.vocab_size, self.kg_vocab_size, MASK_ID, self.k,
+                 self.k, seed ^ 0x5BD1E995, st)
+        return out
+
+    def check_errors(self) -> None:
+        """One tiny D2H copy: raise KeyError if a (source, target) pair named a node without a walk."""
+        if int(self.err.item()):
+            self.err.zero_()
+            raise KeyError("a source / target index is outside the random-walk table "
+                           "(the reference raises KeyError on random_walk_idx_dict[...])")

@@ -130,3 +130,32 @@ def test_classification_head_matches_reference():
     out["loss"].backward()
     for k in meta["grad_keys"]:
         np.testing.assert_allclose(params[k].grad.numpy(), gold["grad::" + k], rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_masking_oracle_properties():
+    """The numpy restatement of the device masking stream (oracle/masking_oracle.py) keeps the reference's invariants
+    (ref:indra_for_pretraining.py:33-77): exactly int(len * 0.15) labels per half, labels = original ids, untouched
+    positions unchanged, deterministic in the seed."""
+    import numpy as np
+
+    from oracle import masking_oracle as mo
+
+    rng = np.random.RandomState(0)
+    ids = rng.randint(0, 300, (4, 64)).astype(np.int64)
+    out, tl, el = mo.mlm_mask(ids, 32, 300, 50, seed=9)
+    out2, tl2, el2 = mo.mlm_mask(ids, 32, 300, 50, seed=9)
+    assert np.array_equal(out, out2) and np.array_equal(tl, tl2) and np.array_equal(el, el2)
+    for lab, off in ((tl, 0), (el, 32)):
+        sel = lab != -100
+        assert (sel.sum(1) == int(32 * 0.15)).all()
+        assert np.array_equal(lab[sel], ids[:, off:off + 32][sel])
+        assert np.array_equal(out[:, off:off + 32][~sel], ids[:, off:off + 32][~sel])
+    assert not np.array_equal(mo.mlm_mask(ids, 32, 300, 50, seed=10)[1], tl)
+    walks = rng.randint(0, 50, (20, 15)).astype(np.int64)
+    text = rng.randint(1, 300, (6, 32)).astype(np.int64)
+    a, att, typ, nsp = mo.assemble_rows(text, np.ones_like(text), np.arange(6), np.arange(6) + 3, walks, seed=4)
+    assert a.shape == (6, 64) and (a[:, 32 + 15] == 102).all() and (a[:, 63] == 102).all()
+    assert np.array_equal(a[:, :32], text) and set(np.unique(nsp)) <= {0, 1} and (typ[:, 32:] == 1).all()
+    for b in range(6):
+        if nsp[b] == 0:
+            assert np.array_equal(a[b, 32:47], walks[b]) and np.array_equal(a[b, 48:63], walks[b + 3])

@@ -102,6 +102,22 @@ def bench_attn():
               flush=True)
 
 
+def bench_data():
+    """On-device batch assembly + dynamic masking (f1) at the bench batch size."""
+    import numpy as np
+    from stonkgs_amd.data import DeviceBatcher
+    B, half, V, K = 64, 256, 28996, 175094
+    rng = np.random.RandomState(0)
+    text = torch.from_numpy(rng.randint(1000, V, (B, half))).cuda()
+    att = torch.ones(B, half, dtype=torch.long, device="cuda")
+    walks = torch.from_numpy(rng.randint(0, K, (K, half // 2 - 1)))
+    src = torch.from_numpy(rng.randint(0, K, B)).cuda()
+    tgt = torch.from_numpy(rng.randint(0, K, B)).cuda()
+    bat = DeviceBatcher(walks, V, K, seed=1)
+    t = timeit(lambda: bat(text, att, src, tgt, 3), iters=50)
+    print(f"device batcher B={B}: {t*1e6:.1f} us per batch (assemble + mask, incl. output allocation)", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "ln"]
     hip.lib()

@@ -300,8 +300,33 @@ def masking_case(pre):
     print("masking: first positions seed 1234:", [i for i, l in enumerate(res["text_lab_1234"]) if l != -100][:8])
 
 
+def splits_case(ft):
+    """G7: the reference's cross-validation splitter (ref:stonkgs_finetuning.py:53-89) on small label frames: plain
+    5-fold, the stratified cut to max_dataset_size followed by 5-fold, and n_splits = 1. Integer indices only."""
+    import pandas as pd
+
+    rng = np.random.RandomState(7)
+    res = {}
+    for name, n, kw in (("plain", 53, {}), ("cut", 90, {"max_dataset_size": 40}), ("single", 31, {"n_splits": 1}),
+                        ("three", 20, {"n_splits": 3, "random_seed": 7})):
+        labels = rng.randint(0, 3, n)
+        df = pd.DataFrame({"input_ids": [[int(i)] for i in range(n)], "labels": labels})
+        out = ft.get_train_test_splits(df, **kw)
+        res[f"{name}_labels"] = labels.astype(np.int64)
+        res[f"{name}_n"] = np.array(len(out))
+        for i, d in enumerate(out):
+            res[f"{name}_train_{i}"] = np.asarray(d["train_idx"], dtype=np.int64)
+            res[f"{name}_test_{i}"] = np.asarray(d["test_idx"], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "g7_splits.npz"), **res)
+    print("splits: plain fold 0 test head:", res["plain_test_0"][:6].tolist())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "splits":     # only (re)generate G7
+        import_reference()                                 # (installs the stub modules the fine-tuning module needs too)
+        splits_case(import_reference_finetuning())
+        return
     torch.manual_seed(0)
     torch.set_num_threads(4)
     sm, pre = import_reference()
@@ -320,6 +345,7 @@ def main():
                         orc.OracleConfig(vocab_size=512, kg_vocab_size=300, hidden_size=128, num_hidden_layers=2,
                                          num_attention_heads=2, intermediate_size=256, max_position_embeddings=256),
                         B=5, seed=300, num_labels=3)
+    splits_case(ft)
 
 
 if __name__ == "__main__":

@@ -142,3 +142,28 @@ def test_embedding_helper_batching_is_host_only_logic():
         next(_batches([{"attention_mask": [1]}], 1))
     with pytest.raises(ValueError):
         next(_batches(rows, 0))
+
+
+def test_cv_splits_match_reference_vectors_and_weighted_f1_matches_sklearn():
+    """f4: get_train_test_splits against vectors made by the REFERENCE's own function (tests/golden/g7_splits.npz,
+    oracle/make_golden.py splits) and the weighted F1 against scikit-learn, which the reference calls."""
+    from sklearn.metrics import f1_score
+
+    from stonkgs_amd.stonkgs_finetuning import INDRADataset, get_train_test_splits, weighted_f1_score
+
+    gold = dict(np.load(GOLDEN + "/g7_splits.npz"))
+    for name, kw in (("plain", {}), ("cut", {"max_dataset_size": 40}), ("single", {"n_splits": 1}),
+                     ("three", {"n_splits": 3, "random_seed": 7})):
+        out = get_train_test_splits({"labels": gold[f"{name}_labels"]}, **kw)
+        assert len(out) == int(gold[f"{name}_n"])
+        for i, d in enumerate(out):
+            assert np.array_equal(d["train_idx"], gold[f"{name}_train_{i}"]), (name, i)
+            assert np.array_equal(d["test_idx"], gold[f"{name}_test_{i}"]), (name, i)
+    rng = np.random.RandomState(0)
+    for _ in range(20):
+        k = rng.randint(2, 6)
+        yt, yp = rng.randint(0, k, 50), rng.randint(0, k, 50)
+        assert weighted_f1_score(yt, yp) == pytest.approx(f1_score(yt, yp, average="weighted"), abs=1e-12)
+    assert weighted_f1_score([0, 0, 1], [0, 0, 0]) == pytest.approx(f1_score([0, 0, 1], [0, 0, 0], average="weighted"))
+    ds = INDRADataset({"input_ids": [[1, 2], [3, 4]], "attention_mask": [[1, 1], [1, 0]], "other": [0, 0]}, [1, 0])
+    assert len(ds) == 2 and set(ds[1]) == {"input_ids", "attention_mask", "labels"} and int(ds[0]["labels"]) == 1

@@ -10,6 +10,15 @@
 
 namespace {
 
+// Sum of squares in a FIXED order: every block leaves its partial sum in a slot, the last block to finish (ticket) adds
+// the slots up in index order. With one atomicAdd per block the result depended on arrival order in its last bits - and
+// with it the clip coefficient and every parameter update, so data-parallel ranks holding identical summed gradients
+// drifted apart by an ulp per step (found with tools/dp2_gloo_gpu.py). One optimizer stream per process is assumed
+// (the slots are library globals).
+constexpr int SUMSQ_MAX_BLOCKS = 1024;
+__device__ float g_sumsq_part[SUMSQ_MAX_BLOCKS];
+__device__ unsigned g_sumsq_ticket = 0;
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
   float acc = 0.f;
   const long n4 = n >> 2;
@@ -21,9 +30,29 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) acc += x[i] * x[i];
   acc = wave_sum(acc);
   __shared__ float part[4];
+  __shared__ bool last;
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&g_sumsq_part[blockIdx.x], part[0] + part[1] + part[2] + part[3], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();   // the slot is visible device-wide before the ticket is taken
+    const unsigned t = __hip_atomic_fetch_add(&g_sumsq_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float tot = 0.f;   // 256 threads: strided slots, then a fixed tree - the same order on every launch and every rank
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+    tot += __hip_atomic_load(&g_sumsq_part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  tot = wave_sum(tot);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+    __hip_atomic_store(&g_sumsq_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  }
 }
 
 // One pass over the flat buffers: p, g, m, v read; p, m, v, bf16(p) written; g zeroed.

@@ -197,3 +197,17 @@ def test_adamw_matches_torch(hip, clip):
         assert (gg == 0).all()  # zero_grad fused
         torch.testing.assert_close(p, ref_p.data, rtol=2e-5, atol=2e-7)
         assert torch.equal(pb, p.to(torch.bfloat16))
+
+
+def test_sumsq_is_bitwise_repeatable(hip):
+    """The global grad-norm feeds the clip coefficient of every parameter update: data-parallel ranks must get the same
+    bits from the same summed gradients, so the reduction order is fixed (no per-block atomics). 20 launches over a
+    buffer large enough for the full 1024-block grid, plus a ragged tail."""
+    n = 50_000_003
+    g = _rand((n,), 1.0, 77, torch.float32)
+    out = torch.zeros(20, device="cuda")
+    for i in range(20):
+        hip.call("stonk_sumsq_f32", hip.ptr(g), n, out[i:].data_ptr(), hip.stream_ptr())
+    torch.cuda.synchronize()
+    assert (out == out[0]).all(), out.tolist()
+    torch.testing.assert_close(out[0], (g.double() ** 2).sum().float(), rtol=1e-5, atol=0)

@@ -6,6 +6,7 @@
 // Replaces: nn.LayerNorm(eps=1e-12) in hf:models/bert/modeling_bert.py BertEmbeddings :98-108,
 // BertSelfOutput :289-293, BertOutput :347-351, BertPredictionHeadTransform :476-480; the KG gather +
 // concat + cast of ref:src/stonkgs/models/stonkgs_model.py:182-200 (K2/K3 in SURVEY.md section 2.3).
+#include <cstdlib>
 #include "common.h"
 #include "stonk_flags.h"
 
@@ -272,6 +273,158 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   }
 }
 
+// ---- lane-layout backward for H = 64 * EPL (EPL = 8, 12, 16: H = 512, 768, 1024) ---------------------------------------
+// The generic kernel above is VALU-bound (~470 VALU instructions per row at H = 768, 69 us for 32 768 rows where the
+// 200 MB it moves would take 25-40 us): a quarter of its lanes idle on the second 8-element chunk (96 chunks over 64
+// lanes), the dropout switches are run-time branches per element, both row sums go through ds_bpermute, and column keys
+// and gamma are re-derived per row. Here every lane owns EPL columns for the whole launch (one 16-byte piece per 512
+// columns plus an 8-byte piece when EPL % 8 == 4), so gamma and the dropout column keys live in registers, the switches are
+// template parameters, and the two row sums use DPP adds + v_readlane (wave-uniform results in SGPRs).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_uniform(float v) {   // all 64 lanes must be active
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror: every lane of a 16-lane row now holds the row's sum
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+template <int EPL, bool DROP_IN, bool DROP_OUT>
+__global__ __launch_bounds__(256) void layernorm_bwd_lane_kernel(
+    const bf16* __restrict__ dy, const bf16* __restrict__ x, const float* __restrict__ mean_in,
+    const float* __restrict__ rstd_in, const float* __restrict__ gamma, bf16* __restrict__ dx,
+    bf16* __restrict__ dx_drop, float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, uint32_t thr32_in,
+    float dscale_in, uint32_t seed_in, uint32_t thr32_out, float dscale_out, uint32_t seed_out, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float sred[];
+  constexpr int H = EPL * 64, NQ = EPL / 8;
+  constexpr bool TAIL = (EPL & 4) != 0;
+  static_assert(EPL % 4 == 0 && EPL >= 4, "lane layout: 4-element granules");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  auto col_of = [&](int e) { return e < NQ * 8 ? (e >> 3) * 512 + lane * 8 + (e & 7) : NQ * 512 + lane * 4 + (e & 3); };
+
+  float gam[EPL], ag[EPL], ab[EPL];
+  uint32_t ck[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    gam[e] = gamma[col_of(e)];
+    ck[e] = stonk_colkey((uint32_t)col_of(e));
+    ag[e] = ab[e] = 0.f;
+  }
+
+  const long stride = (long)gridDim.x * 4;
+  long row = (long)blockIdx.x * 4 + wave;
+  bf16x8 nx8[NQ > 0 ? NQ : 1], nd8[NQ > 0 ? NQ : 1];
+  bf16x4 nx4, nd4;
+  float nmean = 0.f, nrstd = 0.f;
+  auto fetch = [&](long r) {
+    const bf16* xr = x + r * H;
+    const bf16* dr = dy + r * H;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      nx8[q] = *(const bf16x8*)(xr + q * 512 + lane * 8);
+      nd8[q] = *(const bf16x8*)(dr + q * 512 + lane * 8);
+    }
+    if (TAIL) {
+      nx4 = *(const bf16x4*)(xr + NQ * 512 + lane * 4);
+      nd4 = *(const bf16x4*)(dr + NQ * 512 + lane * 4);
+    }
+    nmean = mean_in[r];
+    nrstd = rstd_in[r];
+  };
+  if (row < rows) fetch(row);
+  for (; row < rows; row += stride) {
+    float xh[EPL], g[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      xh[e] = e < NQ * 8 ? (float)nx8[e >> 3][e & 7] : (float)nx4[e & 3];
+      g[e] = e < NQ * 8 ? (float)nd8[e >> 3][e & 7] : (float)nd4[e & 3];
+    }
+    const float mean = nmean, rstd = nrstd;
+    if (row + stride < rows) fetch(row + stride);
+    const uint32_t rk_in = stonk_rowkey((uint32_t)row, seed_in), rk_out = stonk_rowkey((uint32_t)row, seed_out);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      float d = g[e];
+      if (DROP_IN) d = stonk_keep_key(rk_in, ck[e], thr32_in) ? d * dscale_in : 0.f;
+      const float h = (xh[e] - mean) * rstd;
+      ag[e] += d * h;
+      ab[e] += d;
+      const float gg = d * gam[e];
+      xh[e] = h;
+      g[e] = gg;
+      s1 += gg;
+      s2 += gg * h;
+    }
+    const float c1 = wave_sum_uniform(s1) * (1.f / (float)H), c2 = wave_sum_uniform(s2) * (1.f / (float)H);
+    bf16* dxr = dx + row * H;
+    bf16* ddr = dx_drop + row * H;
+    float v[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] = rstd * (g[e] - c1 - xh[e] * c2);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)v[q * 8 + j];
+      *(bf16x8*)(dxr + q * 512 + lane * 8) = o;
+    }
+    if (TAIL) {
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16)v[NQ * 8 + j];
+      *(bf16x4*)(dxr + NQ * 512 + lane * 4) = o;
+    }
+    if (DROP_OUT) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) v[e] = stonk_keep_key(rk_out, ck[e], thr32_out) ? v[e] * dscale_out : 0.f;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)v[q * 8 + j];
+        *(bf16x8*)(ddr + q * 512 + lane * 8) = o;
+      }
+      if (TAIL) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)v[NQ * 8 + j];
+        *(bf16x4*)(ddr + NQ * 512 + lane * 4) = o;
+      }
+    }
+  }
+  if (dgamma) {   // per-wave column partials -> LDS -> one partial row per workgroup (or atomics without a workspace)
+    float* sg = sred;          // [4][H]
+    float* sb = sred + 4 * H;  // [4][H]
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      sg[wave * H + col_of(e)] = ag[e];
+      sb[wave * H + col_of(e)] = ab[e];
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += 256) {
+      const float gs = sg[col] + sg[H + col] + sg[2 * H + col] + sg[3 * H + col];
+      const float bs = sb[col] + sb[H + col] + sb[2 * H + col] + sb[3 * H + col];
+      if (ws) {
+        ws[(long)blockIdx.x * 2 * H + col] = gs;
+        ws[(long)blockIdx.x * 2 * H + H + col] = bs;
+      } else {
+        atomicAdd(dgamma + col, gs);
+        atomicAdd(dbeta + col, bs);
+      }
+    }
+  }
+}
+
 // dgamma[c] += sum_b ws[b][c], dbeta[c] += sum_b ws[b][H + c]: grid (2H/256, 32) - each workgroup sums 1/32 of the
 // partial rows for 256 columns (coalesced 1 KiB row segments), then 32 adders per address finish with atomics.
 __global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ ws, int nb, int H,
@@ -434,6 +587,24 @@ extern "C" int stonk_layernorm_bwd(const void* dy, const void* x, const float* m
   const int grid = ln_grid(rows) < 1024 ? ln_grid(rows) : 1024;
   // workspace (grid x 2H floats) given: partial sums + a reduce kernel instead of contended atomics
   float* ws = (dgamma && partial_ws && ws_floats >= (int64_t)grid * 2 * H) ? partial_ws : nullptr;
+  const bool din = (flags & STONK_LN_DROPOUT) != 0, dout = dx_drop != nullptr;
+#define LN_BWD_LANE(EPL, DI, DO)                                                                                       \
+  hipLaunchKernelGGL((layernorm_bwd_lane_kernel<EPL, DI, DO>), dim3(grid), dim3(256), lds, (hipStream_t)stream,         \
+                     (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (bf16*)dx, (bf16*)dx_drop, dgamma, dbeta,      \
+                     (long)rows, stonk_drop_thr32(drop_p_in), 1.f / (1.f - drop_p_in), stonk_seed_mix(seed_in),         \
+                     stonk_drop_thr32(drop_p_out), 1.f / (1.f - drop_p_out), stonk_seed_mix(seed_out), ws)
+#define LN_BWD_LANE_H(EPL)                                  \
+  do {                                                      \
+    if (din && dout) LN_BWD_LANE(EPL, true, true);          \
+    else if (din) LN_BWD_LANE(EPL, true, false);            \
+    else if (dout) LN_BWD_LANE(EPL, false, true);           \
+    else LN_BWD_LANE(EPL, false, false);                    \
+  } while (0)
+  const bool generic_only = getenv("STONK_LN_V1") != nullptr;   // A/B switch: the generic kernel for every H
+  if (H == 768 && !generic_only) LN_BWD_LANE_H(12);
+  else if (H == 1024 && !generic_only) LN_BWD_LANE_H(16);
+  else if (H == 512 && !generic_only) LN_BWD_LANE_H(8);
+  else
   LN_DISPATCH(H, hipLaunchKernelGGL((layernorm_bwd_kernel<CPL>), dim3(grid), dim3(256), lds, (hipStream_t)stream,
                                     (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (bf16*)dx, (bf16*)dx_drop,
                                     dgamma, dbeta, (long)rows, H, flags, stonk_drop_thr32(drop_p_in),

@@ -10,6 +10,8 @@ B=64 needs ~12 GB), nothing is recomputed except attention probabilities.
 """
 from __future__ import annotations
 
+import contextlib
+
 import math
 import os
 from typing import Callable, Dict, List, Optional
@@ -77,6 +79,11 @@ class Engine:
         # stream (dgrad through GELU) then takes the 128x128 kernel, whose grid the hardware schedules dynamically.
         self.comm_overlap = False
         self._wstream: Optional[torch.cuda.Stream] = None
+        # The optimizer (grad-norm, AdamW, W^T refresh: ~2 ms of HBM-bound work) runs on a third stream; the next step's
+        # frozen-backbone forward reads none of what it writes and starts beside it. `wait_params()` orders the current
+        # stream after the last parameter write - called before the first trainable weight is read and by every accessor.
+        self._opt_stream: Optional[torch.cuda.Stream] = None
+        self._params_ready: Optional[torch.cuda.Event] = None
         self._wgrad_done: Dict[int, torch.cuda.Event] = {}   # layer parity -> side-stream event after its last wgrad
 
     # ------------------------------------------------------------------ plumbing
@@ -89,6 +96,28 @@ class Engine:
             t = (torch.zeros if zero else torch.empty)(max(n, 1), dtype=dtype, device=self.device)
             self.ws[name] = t
         return t[:n].view(shape)
+
+    @contextlib.contextmanager
+    def optimizer_stream(self, enabled: bool = True):
+        """Run the body on the optimizer stream, ordered after everything enqueued so far on the current stream; on
+        exit the engine remembers the event that marks the parameters as final (see `wait_params`)."""
+        if not enabled:
+            yield
+            return
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=self.device)
+        self._opt_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._opt_stream):
+            yield
+            ev = torch.cuda.Event()
+            ev.record(self._opt_stream)
+        self._params_ready = ev
+
+    def wait_params(self) -> None:
+        """Order the current stream after the pending optimizer step, if any (no host synchronisation)."""
+        ev, self._params_ready = self._params_ready, None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def ln_ws(self) -> torch.Tensor:
         """Partial-sum workspace of the LayerNorm backward kernels (1024 workgroups x 2H floats)."""
@@ -348,6 +377,7 @@ class Engine:
         p_att = cfg.attention_probs_dropout_prob if training else 0.0
         # F1 frozen backbone (no attention mask: quirk Q5)
         text_hidden = self.backbone_fwd(input_ids, S, B, half, training)
+        self.wait_params()   # everything above read frozen weights only; from here on the trainable ones
         # F2 gather + concat + embeddings LayerNorm
         sum0 = self.buf("e.sum0", (T, H))
         x = self.buf("e.x0", (T, H))

@@ -255,7 +255,23 @@ class STonKGsForPreTraining(nn.Module):
                                       "HBM buffers and cannot be moved or cast")
         return self
 
+    # Accessors order the caller's stream after an optimizer step still running on the optimizer stream
+    # (Engine.wait_params): whatever they hand out is final for work enqueued on the current stream.
+    def _wait_params(self) -> None:
+        eng = self.__dict__.get("engine")
+        if eng is not None:
+            eng.wait_params()
+
+    def state_dict(self, *args, **kwargs):
+        self._wait_params()
+        return super().state_dict(*args, **kwargs)
+
+    def named_parameters(self, *args, **kwargs):
+        self._wait_params()
+        return super().named_parameters(*args, **kwargs)
+
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False, _refresh: bool = True):
+        self._wait_params()
         res = super().load_state_dict(state_dict, strict=strict)
         if _refresh:
             self.refresh()
@@ -271,6 +287,7 @@ class STonKGsForPreTraining(nn.Module):
 
     def named_grad_views(self) -> Dict[str, torch.Tensor]:
         """name -> view into the flat gradient buffer (stable across zero_grad(set_to_none=True))."""
+        self._wait_params()
         return self._grad_views
 
     # -------------------------------------------------------------- loaders

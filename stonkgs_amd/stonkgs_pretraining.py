@@ -45,6 +45,9 @@ class TrainingArguments:
     save_total_limit: int = 5
     seed: int = 42
     ddp_bucket_mb: float = 64.0
+    # clip + AdamW + W^T refresh (and the tail of the gradient all-reduce) on their own stream, beside the next step's
+    # frozen-backbone forward; parameters read through the model's accessors or after torch.cuda.synchronize() are final
+    optimizer_overlap: bool = True
 
 
 def linear_schedule_lr(base_lr: float, step: int, max_steps: int, warmup: int = 0) -> float:
@@ -77,6 +80,7 @@ class FusedAdamW:
                  1.0 - b2 ** self.step_count, self.gnorm_sq.data_ptr(), self.max_grad_norm, grad_scale, st)
 
     def last_grad_norm(self, grad_scale: float = 1.0) -> float:
+        torch.cuda.synchronize(self.gnorm_sq.device)   # the optimizer may have run on its own stream
         return float(self.gnorm_sq.sqrt().item()) * grad_scale
 
     def zero_grad(self) -> None:
@@ -199,10 +203,11 @@ class Trainer:
         hook = self.sync.on_segment_done if last else None
         loss = model.forward_backward(inputs, gscale=1.0 / gas, on_segment_done=hook)
         if last:
-            scale = self.sync.finish()
             lr = linear_schedule_lr(self.args.learning_rate, self.global_step, self.args.max_steps, self.args.warmup_steps)
-            self.optimizer.step(lr, grad_scale=scale)
-            model.engine.refresh_derived(bf16_mirror=False)
+            with model.engine.optimizer_stream(self.args.optimizer_overlap):
+                scale = self.sync.finish()
+                self.optimizer.step(lr, grad_scale=scale)
+                model.engine.refresh_derived(bf16_mirror=False)
             self.global_step += 1
         return loss
 
@@ -239,6 +244,7 @@ class Trainer:
 
     # checkpoint / resume (ref:stonkgs_pretraining.py:185-186,196-223: save_steps, save_total_limit, resume)
     def save_checkpoint(self) -> str:
+        self.model.engine.wait_params()
         d = os.path.join(self.args.output_dir, f"checkpoint-{self.global_step}")
         self.model.save_pretrained(d)
         torch.save(self.optimizer.state_dict(), os.path.join(d, "optimizer.pt"))

@@ -24,7 +24,15 @@ torch.cuda.synchronize()
 res = {True: [], False: []}
 for rnd in range(6):
     for val in (True, False):
-        setattr(model.engine, attr, val)
+        if attr.startswith("env:"):   # a library switch read per call with getenv: True = variable set
+            if val:
+                os.environ[attr[4:]] = "1"
+            else:
+                os.environ.pop(attr[4:], None)
+        elif attr.startswith("args:"):   # a TrainingArguments switch
+            setattr(tr.args, attr[5:], val)
+        else:
+            setattr(model.engine, attr, val)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(10):

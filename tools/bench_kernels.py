@@ -71,6 +71,11 @@ def bench_ln():
     t = timeit(lambda: hip.call("stonk_layernorm_bwd", hip.ptr(y), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(g),
                                 hip.ptr(dx), 0, hip.ptr(dg), hip.ptr(db), rows, H, 0, 0.0, 0, 0.0, 0, hip.ptr(LN_WS), LN_WS.numel(), hip.stream_ptr()))
     print(f"layernorm_bwd {rows}x{H}: {t*1e6:.1f} us  {rows*H*6/t/1e9:.0f} GB/s", flush=True)
+    dxd = torch.empty_like(x)
+    t = timeit(lambda: hip.call("stonk_layernorm_bwd", hip.ptr(y), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(g),
+                                hip.ptr(dx), hip.ptr(dxd), hip.ptr(dg), hip.ptr(db), rows, H, 0, 0.0, 0, 0.1, 5, hip.ptr(LN_WS),
+                                LN_WS.numel(), hip.stream_ptr()))
+    print(f"layernorm_bwd + dropped copy {rows}x{H}: {t*1e6:.1f} us  {rows*H*8/t/1e9:.0f} GB/s", flush=True)
 
 
 

@@ -38,6 +38,7 @@ def main():
         b = synthetic_batch(B, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=100 + 10 * step + rank)
         losses.append(float(tr.training_step(model, b)))
     model.engine.check_errors()
+    model.engine.wait_params()   # the optimizer runs on its own stream
     flat = model._store.data.detach().clone()
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
@@ -64,6 +65,7 @@ def main():
         for step in range(2):
             for r in range(world):
                 tr2.training_step(ref, synthetic_batch(B, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=100 + 10 * step + r))
+        ref.engine.wait_params()
         d = (ref._store.data - flat).abs().max().item()
         scale = (ref._store.data.abs().max().item())
         print(f"ranks identical: {same}; losses {losses}; max |dp - accumulated| = {d:.3e} (param scale {scale:.2f})", flush=True)

@@ -94,11 +94,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU over RCCL; STONK_DIST_BACKEND=gloo lets several ranks share one card (a rehearsal of the N > 1
+    # control flow on a one-GPU box - never a measurement)
+    backend = os.environ.get("STONK_DIST_BACKEND", "nccl")
+    local_dev = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend)
     from stonkgs_amd.config import STonKGsConfig
     from stonkgs_amd.data import synthetic_batch
     from stonkgs_amd.stonkgs_model import STonKGsForPreTraining
@@ -142,16 +149,18 @@ def main():
 
     roofline = None
     gemm_all = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline:
         # dominant kernel of the step = gemm_tn_w4_kernel (weight + bias gradients of the FFN and fused-QKV linears, 36
         # launches/step; profiles/ has the rocprofv3 kernel-trace of the same command): per-launch HIP events on the
         # launch stream over two extra steps; achieved = algorithmic FLOPs (2 * M' * N' * tokens per launch) / summed
         # durations
+        # (every rank runs the two steps - they contain the gradient all-reduce - and times its own launches; rank 0 reports)
         from stonkgs_amd.engine import GemmTimer
 
         model.engine.gemm_timer = GemmTimer()
         for i in range(2):
             trainer.training_step(model, batches[i % len(batches)])
+        torch.cuda.synchronize()
         s = model.engine.gemm_timer.summarize("tn_w4")
         a = model.engine.gemm_timer.summarize(None)
         model.engine.gemm_timer = None

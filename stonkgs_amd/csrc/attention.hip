@@ -153,15 +153,36 @@ __device__ __forceinline__ void stage_store(const Stage2& s, char* tile, int tid
 // and the kernel with the key on the lane does the same with the row key. The 1/(1-p) factor never touches an
 // element: it is folded into the output normalisation (forward, dV) or into delta and the final scale (dQ, dK).
 
+// Workgroup -> (128-row block, head, sequence). Workgroups are dispatched round-robin over the 8 XCDs in linear order, so
+// with the plain grid mapping the S/128 blocks of one head (which all read that head's K and V, or Q and dO) land on
+// different XCDs and each L2 fetches the head again: 455 MB of fabric reads per forward launch against 151 MB of Q/K/V
+// (rocprofv3 FETCH_SIZE). Here every XCD takes one contiguous run of the linear (sequence, head, block) order, so a
+// head's blocks share an L2 and run at the same time.
+struct AttnBlock { int xb, h, b; };
+__device__ __forceinline__ AttnBlock attn_block() {
+  const int nx = gridDim.x, nh = gridDim.y;
+  const int n = nx * nh * gridDim.z;
+  const int lin = blockIdx.x + nx * (blockIdx.y + nh * blockIdx.z);
+  const int q = n >> 3, rm = n & 7, x = lin & 7;
+  const int l = ((x < rm) ? x * (q + 1) : rm * (q + 1) + (x - rm) * q) + (lin >> 3);
+  AttnBlock o;
+  o.xb = l % nx;
+  const int t = l / nx;
+  o.h = t % nh;
+  o.b = t / nh;
+  return o;
+}
+
 // ------------------------------------------------------------------ forward
 template <bool HAS_MASK, bool DROPOUT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGEB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const AttnBlock blk = attn_block();
+  const int b = blk.b, h = blk.h;
   const int S = p.S;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blk.xb * 128 + wave * 32;
   const long tok0 = (long)b * S;
   const float sc2 = p.scale * LOG2E;
 
@@ -284,9 +305,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGEB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const AttnBlock blk = attn_block();
+  const int b = blk.b, h = blk.h;
   const int S = p.S;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blk.xb * 128 + wave * 32;
   const long tok0 = (long)b * S;
   const float sc2 = p.scale * LOG2E;
 
@@ -402,9 +424,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGEB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const AttnBlock blk = attn_block();
+  const int b = blk.b, h = blk.h;
   const int S = p.S;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int k0 = blk.xb * 128 + wave * 32;
   const long tok0 = (long)b * S;
   const float sc2 = p.scale * LOG2E;
 

@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
   const int nk_per = (nk_total + p.split_k - 1) / p.split_k;
   const int per_split = ntm * ntn;
   const int total = per_split * p.split_k;
-  const bool one_shot = ((int)gridDim.x == total);
+  // one tile per workgroup (a grid sized for the capacity M may exceed the live tile count of a device-side M: the
+  // surplus workgroups leave at once, the live ones are workgroups 0 .. total-1 and are remapped among themselves)
+  const bool one_shot = ((int)gridDim.x >= total);
 
   // per-lane fragment read offsets (bytes inside a tile): row = base + (lane & 15), swizzle = lane & 7
   const int frag_row = lane & 15;

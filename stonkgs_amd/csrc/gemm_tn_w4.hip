@@ -79,9 +79,10 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const GemmArgs p) {
   auto get_work = [&](int w, Work& o) -> bool {
     if (w >= total) return false;
     int idx = w;
-    if ((G & 7) == 0) {
+    {   // any grid size: XCD x = b & 7 hosts ceil((G - x) / 8) workgroups; give them one contiguous run of items
       const int r = w / G, b = w - r * G;
-      const int cand = r * G + (b & 7) * (G >> 3) + (b >> 3);
+      const int x = b & 7, base = G >> 3, rem = G & 7;
+      const int cand = r * G + x * base + (x < rem ? x : rem) + (b >> 3);
       if ((r + 1) * G <= total) idx = cand;
     }
     const int ks = idx / per_split;

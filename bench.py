@@ -24,6 +24,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# gemm_tn_w4_kernel, average of its 36 launches per step: 303.8 MB fetched (FETCH_SIZE doubled, the gfx950 correction of
+# MI355X_MICROARCH.md) + 45.0 MB of float atomics written (profiles/r01_final_pmc_traffic.csv)
+TN_W4_TRAFFIC_BYTES = 348.8e6
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
 # algorithmic GFLOP per text-triple pair, 12L/768/S=512, label-sparse decoders
 GFLOP_PER_PAIR_STEP = 373.4
@@ -168,7 +171,11 @@ def main():
         roofline = {"bound": "mfma", "kernel": "gemm_tn_w4_kernel (bf16 MFMA 32x32x16, 256x256 tiles over 64-token steps, four "
                                                "waves, transposed LDS reads, split-K fp32 atomics)",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": TN_W4_TRAFFIC_BYTES,
+                    "traffic_note": "bytes per launch at the L2's memory side = 2 x FETCH_SIZE + WRITE_SIZE (KiB, separate "
+                                    "rocprofv3 --pmc passes over this command, profiles/r01_final_pmc_traffic.csv) against "
+                                    "234 MB of operands + 9.4 MB of output per launch; a recorded constant - counters "
+                                    "cannot be read from inside the bench",
                     "launches_per_step": s["launches"] // 2,
                     "avg_launch_us": round(s["seconds"] / s["launches"] * 1e6, 1),
                     "avg_launch_gflop": round(s["flops"] / s["launches"] / 1e9, 2)}

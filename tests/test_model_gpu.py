@@ -113,6 +113,33 @@ def test_two_optimizer_steps_match_reference_golden(hip):
             assert (params[k].detach().cpu() - torch.from_numpy(gold["after2::" + k])).abs().max() <= 4.5e-4
 
 
+def test_optimizer_stream_is_equivalent_to_serial_order(hip):
+    """The optimizer on its own stream beside the next step's frozen-backbone forward (TrainingArguments.optimizer_overlap)
+    against the serial order, three steps from the same state with the same dropout seeds: same losses and grad-norm,
+    parameters equal except where split-K atomics reorder fp32 addends (last-bit gradient differences; Adam turns those
+    into visible steps only for the analytically-zero gradients such as key.bias, hence the fraction-based bound)."""
+    from stonkgs_amd.stonkgs_pretraining import Trainer, TrainingArguments
+
+    cfg, sd, tsv_rows, batch, gold, meta = load_case("g2_hipsmall")
+    res = []
+    for overlap in (True, False):
+        model = _build(cfg, sd, tsv_rows)
+        model.engine.seed_base = 0x5710
+        tr = Trainer(model, TrainingArguments(max_steps=200, learning_rate=1e-4, per_device_train_batch_size=3,
+                                              optimizer_overlap=overlap))
+        losses = [float(tr.training_step(model, batch)) for _ in range(3)]
+        assert (model.engine._params_ready is not None) == overlap   # the overlapped step leaves its event pending
+        params = {k: v.detach().clone() for k, v in model.named_parameters()}   # (accessor waits for the optimizer)
+        assert model.engine._params_ready is None
+        res.append((losses, params, tr.optimizer.last_grad_norm()))
+    (l0, p0, g0), (l1, p1, g1) = res
+    assert l0 == pytest.approx(l1, rel=1e-4)
+    assert g0 == pytest.approx(g1, rel=1e-4)
+    diff = torch.cat([(p0[k] - p1[k]).abs().flatten() for k in p0])
+    assert float(diff.max()) <= 6.1e-4            # three steps of lr = 1e-4 in opposite directions at the very worst
+    assert float((diff > 2e-6).float().mean()) < 2e-3
+
+
 def test_against_oracle_on_fresh_batch_and_masks(g2):
     """Oracle (pinned by test_oracle_golden.py) on a new batch with different padding, B = 5."""
     from stonkgs_amd.data import synthetic_batch

@@ -425,6 +425,82 @@ __global__ __launch_bounds__(256) void layernorm_bwd_lane_kernel(
   }
 }
 
+// Forward in the same lane-owned-column layout (H = 64 * EPL): gamma / beta in registers for the whole launch, the next row's
+// loads in flight while the current one is reduced, both statistics by DPP adds + v_readlane.
+template <int EPL, bool DROP>
+__global__ __launch_bounds__(256) void layernorm_fwd_lane_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, bf16* __restrict__ y,
+                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                 long rows, float eps, uint32_t thr32, float dscale,
+                                                                 uint32_t seed) {
+  constexpr int H = EPL * 64, NQ = EPL / 8;
+  constexpr bool TAIL = (EPL & 4) != 0;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  auto col_of = [&](int e) { return e < NQ * 8 ? (e >> 3) * 512 + lane * 8 + (e & 7) : NQ * 512 + lane * 4 + (e & 3); };
+  float gam[EPL], bet[EPL];
+  uint32_t ck[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    gam[e] = gamma[col_of(e)];
+    bet[e] = beta[col_of(e)];
+    ck[e] = stonk_colkey((uint32_t)col_of(e));
+  }
+  const long stride = (long)gridDim.x * 4;
+  long row = (long)blockIdx.x * 4 + wave;
+  bf16x8 nx8[NQ > 0 ? NQ : 1];
+  bf16x4 nx4;
+  auto fetch = [&](long r) {
+    const bf16* xr = x + r * H;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) nx8[q] = *(const bf16x8*)(xr + q * 512 + lane * 8);
+    if (TAIL) nx4 = *(const bf16x4*)(xr + NQ * 512 + lane * 4);
+  };
+  if (row < rows) fetch(row);
+  for (; row < rows; row += stride) {
+    float v[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] = e < NQ * 8 ? (float)nx8[e >> 3][e & 7] : (float)nx4[e & 3];
+    if (row + stride < rows) fetch(row + stride);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) s += v[e];
+    const float mean = wave_sum_uniform(s) * (1.f / (float)H);
+    float q2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      v[e] -= mean;
+      q2 += v[e] * v[e];
+    }
+    const float rstd = rsqrtf(wave_sum_uniform(q2) * (1.f / (float)H) + eps);
+    if (lane == 0 && mean_out) {
+      mean_out[row] = mean;
+      rstd_out[row] = rstd;
+    }
+    const uint32_t rk = stonk_rowkey((uint32_t)row, seed);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      float o = v[e] * rstd * gam[e] + bet[e];
+      if (DROP) o = stonk_keep_key(rk, ck[e], thr32) ? o * dscale : 0.f;
+      v[e] = o;
+    }
+    bf16* yr = y + row * H;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)v[q * 8 + j];
+      *(bf16x8*)(yr + q * 512 + lane * 8) = o;
+    }
+    if (TAIL) {
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16)v[NQ * 8 + j];
+      *(bf16x4*)(yr + NQ * 512 + lane * 4) = o;
+    }
+  }
+}
+
 // dgamma[c] += sum_b ws[b][c], dbeta[c] += sum_b ws[b][H + c]: grid (2H/256, 32) - each workgroup sums 1/32 of the
 // partial rows for 256 columns (coalesced 1 KiB row segments), then 32 adders per address finish with atomics.
 __global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ ws, int nb, int H,
@@ -568,6 +644,24 @@ extern "C" int stonk_layernorm_fwd(const void* x, const float* gamma, const floa
   if (rows == 0) return STONK_OK;
   const uint32_t thr = stonk_drop_thr32(drop_p);
   const float ds = 1.f / (1.f - drop_p);
+  const bool generic_only = getenv("STONK_LN_V1") != nullptr;   // A/B switch: the generic kernels for every H
+  const bool drop = (flags & STONK_LN_DROPOUT) != 0;
+#define LN_FWD_LANE(EPL)                                                                                                \
+  do {                                                                                                                  \
+    const int grid = ln_grid(rows) < 1024 ? ln_grid(rows) : 1024;                                                       \
+    if (drop)                                                                                                           \
+      hipLaunchKernelGGL((layernorm_fwd_lane_kernel<EPL, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream,         \
+                         (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, (long)rows, eps, thr, ds,                   \
+                         stonk_seed_mix(seed));                                                                         \
+    else                                                                                                                \
+      hipLaunchKernelGGL((layernorm_fwd_lane_kernel<EPL, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream,        \
+                         (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, (long)rows, eps, thr, ds,                   \
+                         stonk_seed_mix(seed));                                                                         \
+  } while (0)
+  if (H == 768 && !generic_only) LN_FWD_LANE(12);
+  else if (H == 1024 && !generic_only) LN_FWD_LANE(16);
+  else if (H == 512 && !generic_only) LN_FWD_LANE(8);
+  else
   LN_DISPATCH(H, hipLaunchKernelGGL((layernorm_fwd_kernel<CPL>), dim3(ln_grid(rows)), dim3(256), 0,
                                     (hipStream_t)stream, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, (long)rows,
                                     H, eps, flags, thr, ds, stonk_seed_mix(seed)));

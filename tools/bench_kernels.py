@@ -80,6 +80,22 @@ def bench_ln():
 
 
 
+def bench_xent():
+    cap, N = 16384, 175094
+    npad = (N + 127) // 128 * 128
+    for cnt_v in (2432, 2048, 1500):
+        logits = torch.randn(cnt_v + 64, npad, device="cuda")
+        dl = torch.empty(cnt_v + 64, npad, device="cuda", dtype=torch.bfloat16)
+        tg = torch.randint(0, N, (cap,), device="cuda", dtype=torch.int32)
+        cnt = torch.tensor([cnt_v], device="cuda", dtype=torch.int32)
+        acc = torch.zeros(1, device="cuda")
+        err = torch.zeros(1, device="cuda", dtype=torch.int32)
+        t = timeit(lambda: hip.call("stonk_softmax_xent_fwd_bwd", hip.ptr(logits), npad, N, npad, hip.ptr(tg), hip.ptr(cnt),
+                                    hip.ptr(acc), hip.ptr(dl), npad, 1.0, cnt_v + 64, hip.ptr(err), hip.stream_ptr()), iters=10)
+        print(f"softmax_xent {cnt_v} rows x {N}: {t*1e6:.1f} us  {cnt_v*npad*10/t/1e9:.0f} GB/s (2 fp32 reads + bf16 write)",
+              flush=True)
+
+
 def bench_attn():
     B, S, NH = 64, 512, 12
     H = NH * 64

@@ -22,6 +22,7 @@ EPI_RESID = 1 << 4
 EPI_SAVE_PREACT = 1 << 5
 EPI_GELU_BWD = 1 << 6
 EPI_DROPOUT = 1 << 7
+EPI_AUX_GRAD = 1 << 8   # aux = gelu'(pre-activation): stored by SAVE_PREACT (with GELU), multiplied in by GELU_BWD
 EPI_DEBUG_REGSTAGE = 1 << 16
 EPI_DEBUG_V1 = 1 << 17
 EPI_DEBUG_V2 = 1 << 18

@@ -66,6 +66,10 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * 0.39894228040143267794f * e;
 }
 
+// what SAVE_PREACT stores / what GELU_BWD multiplies by, with and without STONK_EPI_AUX_GRAD
+__device__ __forceinline__ float gelu_saved(float pre, bool aux_grad) { return aux_grad ? gelu_erf_grad(pre) : pre; }
+__device__ __forceinline__ float gelu_factor(float aux, bool aux_grad) { return aux_grad ? aux : gelu_erf_grad(aux); }
+
 // Counter-based dropout RNG. Forward and backward regenerate the same keep-mask from (seed, row, column); nothing is
 // stored. An element's 32-bit counter is  x = (row * G_ROW + mix(seed)) ^ (column * G_COL)  - both keys are linear, so a
 // lane walking rows or columns advances them with one add - followed by two 24-bit multiply rounds (v_mad_u32_u24 /

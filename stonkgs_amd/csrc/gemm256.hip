@@ -582,8 +582,8 @@ int stonk_gemm256_launch(const GemmArgs& a, int out_mode, hipStream_t st) {
   const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.split_k;
   const int grid = (int)(tiles < n_cu ? tiles : n_cu);
   constexpr int B = STONK_EPI_BIAS, G = STONK_EPI_GELU, SV = STONK_EPI_SAVE_PREACT, GB = STONK_EPI_GELU_BWD,
-                R = STONK_EPI_RESID, D = STONK_EPI_DROPOUT;
-  const int epi = a.flags & (B | G | SV | GB | R | D);
+                R = STONK_EPI_RESID, D = STONK_EPI_DROPOUT, AG = STONK_EPI_AUX_GRAD;
+  const int epi = a.flags & (B | G | SV | GB | R | D | AG);
   if (out_mode == 1) return epi == 0 ? launch256<1, 0>(a, grid, st) : launch256<1, -1>(a, grid, st);
   if (out_mode == 2) return launch256<2, 0>(a, grid, st);
   switch (epi) {   // the combinations the STonKGs step uses are compiled with constant flags
@@ -592,6 +592,8 @@ int stonk_gemm256_launch(const GemmArgs& a, int out_mode, hipStream_t st) {
     case B | G: return launch256<0, B | G>(a, grid, st);
     case B | G | SV: return launch256<0, B | G | SV>(a, grid, st);
     case GB: return launch256<0, GB>(a, grid, st);
+    case B | G | SV | AG: return launch256<0, B | G | SV | AG>(a, grid, st);
+    case GB | AG: return launch256<0, GB | AG>(a, grid, st);
     case R: return launch256<0, R>(a, grid, st);
     case B | R: return launch256<0, B | R>(a, grid, st);
     default: return launch256<0, -1>(a, grid, st);

@@ -224,7 +224,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
           f32x4 v = acc[i][j] * p.alpha;
           if (EPI & STONK_EPI_BIAS) v += bq[j];
           if (EPI & STONK_EPI_SAVE_PREACT) {
-            bf16x4 u = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            constexpr bool AG = (EPI & STONK_EPI_AUX_GRAD) != 0;
+            bf16x4 u = {(bf16)gelu_saved(v[0], AG), (bf16)gelu_saved(v[1], AG), (bf16)gelu_saved(v[2], AG),
+                        (bf16)gelu_saved(v[3], AG)};
             *(bf16x4*)(p.aux + (long)m * p.ldaux + n) = u;
           }
           if (EPI & STONK_EPI_GELU) {
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
           }
           if (EPI & STONK_EPI_GELU_BWD) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)sa[i][j][r]);
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_factor((float)sa[i][j][r], (EPI & STONK_EPI_AUX_GRAD) != 0);
           }
           if (EPI & STONK_EPI_DROPOUT) {
             const uint32_t rk = stonk_rowkey((uint32_t)m, p.seed), ck = stonk_colkey((uint32_t)n);
@@ -305,6 +307,8 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   if (flags & STONK_EPI_RESID) STONK_CHECK_ARG(resid && ldr % 4 == 0, STONK_EINVAL);
   if (flags & (STONK_EPI_SAVE_PREACT | STONK_EPI_GELU_BWD)) STONK_CHECK_ARG(aux && ldaux % 4 == 0, STONK_EINVAL);
   if (flags & STONK_EPI_DROPOUT) STONK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, STONK_EINVAL);
+  if (flags & STONK_EPI_AUX_GRAD)   // a modifier of the two aux users; storing gelu' only makes sense next to the GELU
+    STONK_CHECK_ARG((flags & STONK_EPI_GELU_BWD) || ((flags & STONK_EPI_SAVE_PREACT) && (flags & STONK_EPI_GELU)), STONK_EINVAL);
   if (M == 0) return STONK_OK;
 
   GemmArgs a;
@@ -361,8 +365,8 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   const int grid = (int)(tiles < cap ? tiles : cap);
   const bool glds = !(flags & STONK_EPI_DEBUG_REGSTAGE);
   constexpr int Bi = STONK_EPI_BIAS, G = STONK_EPI_GELU, SV = STONK_EPI_SAVE_PREACT, GB = STONK_EPI_GELU_BWD,
-                R = STONK_EPI_RESID, D = STONK_EPI_DROPOUT;
-  const int epi = flags & (Bi | G | SV | GB | R | D);
+                R = STONK_EPI_RESID, D = STONK_EPI_DROPOUT, AG = STONK_EPI_AUX_GRAD;
+  const int epi = flags & (Bi | G | SV | GB | R | D | AG);
   if (!glds) {
     switch (out_mode) {
       case STONK_EPI_OUT_BF16: return launch<0, false, -1>(a, grid, st);
@@ -377,6 +381,8 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
     case Bi: return launch<0, true, Bi>(a, grid, st);
     case Bi | G | SV: return launch<0, true, Bi | G | SV>(a, grid, st);
     case GB: return launch<0, true, GB>(a, grid, st);
+    case Bi | G | SV | AG: return launch<0, true, Bi | G | SV | AG>(a, grid, st);
+    case GB | AG: return launch<0, true, GB | AG>(a, grid, st);
     case R: return launch<0, true, R>(a, grid, st);
     case Bi | R: return launch<0, true, Bi | R>(a, grid, st);
     case Bi | R | D: return launch<0, true, Bi | R | D>(a, grid, st);

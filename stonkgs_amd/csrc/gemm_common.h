@@ -38,7 +38,9 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& p, int flags, int m, int n) {
   if (flags & STONK_EPI_BIAS) v += *(const f32x4*)(p.bias + n);
   if (flags & STONK_EPI_SAVE_PREACT) {
-    bf16x4 u = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    const bool ag = (flags & STONK_EPI_AUX_GRAD) != 0;
+    bf16x4 u = {(bf16)gelu_saved(v[0], ag), (bf16)gelu_saved(v[1], ag), (bf16)gelu_saved(v[2], ag),
+                (bf16)gelu_saved(v[3], ag)};
     *(bf16x4*)(p.aux + (long)m * p.ldaux + n) = u;
   }
   if (flags & STONK_EPI_GELU) {
@@ -48,7 +50,7 @@ __device__ __forceinline__ f32x4 epilogue4(f32x4 v, const GemmArgs& p, int flags
   if (flags & STONK_EPI_GELU_BWD) {
     const bf16x4 u = *(const bf16x4*)(p.aux + (long)m * p.ldaux + n);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad((float)u[r]);
+    for (int r = 0; r < 4; ++r) v[r] *= gelu_factor((float)u[r], (flags & STONK_EPI_AUX_GRAD) != 0);
   }
   if (flags & STONK_EPI_DROPOUT) {
     const uint32_t rk = stonk_rowkey((uint32_t)m, p.seed), ck = stonk_colkey((uint32_t)n);
@@ -78,7 +80,7 @@ __device__ __forceinline__ void epilogue8(float (&v)[8], const GemmArgs& p, int 
   if (flags & STONK_EPI_SAVE_PREACT) {
     bf16x8 u;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) u[r] = (bf16)v[r];
+    for (int r = 0; r < 8; ++r) u[r] = (bf16)gelu_saved(v[r], (flags & STONK_EPI_AUX_GRAD) != 0);
     *(bf16x8*)(p.aux + (long)m * p.ldaux + n) = u;
   }
   if (flags & STONK_EPI_GELU) {
@@ -88,7 +90,7 @@ __device__ __forceinline__ void epilogue8(float (&v)[8], const GemmArgs& p, int 
   if (flags & STONK_EPI_GELU_BWD) {
     const bf16x8 u = *(const bf16x8*)(p.aux + (long)m * p.ldaux + n);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad((float)u[r]);
+    for (int r = 0; r < 8; ++r) v[r] *= gelu_factor((float)u[r], (flags & STONK_EPI_AUX_GRAD) != 0);
   }
   if (flags & STONK_EPI_DROPOUT) {
     const uint32_t rk = stonk_rowkey((uint32_t)m, p.seed), ck = stonk_colkey((uint32_t)n);
@@ -135,7 +137,7 @@ __device__ __forceinline__ void epilogue8_pre(float (&v)[8], const GemmArgs& p, 
   if (flags & STONK_EPI_SAVE_PREACT) {
     bf16x8 u;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) u[r] = (bf16)v[r];
+    for (int r = 0; r < 8; ++r) u[r] = (bf16)gelu_saved(v[r], (flags & STONK_EPI_AUX_GRAD) != 0);
     *(bf16x8*)(p.aux + (long)m * p.ldaux + n) = u;
   }
   if (flags & STONK_EPI_GELU) {
@@ -144,7 +146,7 @@ __device__ __forceinline__ void epilogue8_pre(float (&v)[8], const GemmArgs& p, 
   }
   if (flags & STONK_EPI_GELU_BWD) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad((float)s.aux[r]);
+    for (int r = 0; r < 8; ++r) v[r] *= gelu_factor((float)s.aux[r], (flags & STONK_EPI_AUX_GRAD) != 0);
   }
   if (flags & STONK_EPI_DROPOUT) {
     const uint32_t rk = stonk_rowkey((uint32_t)m, p.seed), ck = stonk_colkey((uint32_t)n);

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
             if (flags & STONK_EPI_SAVE_PREACT) {
               bf16x8 u;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) u[e] = (bf16)v[e];
+              for (int e = 0; e < 8; ++e) u[e] = (bf16)gelu_saved(v[e], (flags & STONK_EPI_AUX_GRAD) != 0);
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(eu32x4, u), rX, voX + mrow * ldx_b + n0 * 2, 0, 0);
             }
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -488,8 +488,8 @@ int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, hipStream_t st) {
   const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.split_k;
   const int grid = (int)(tiles < n_cu ? tiles : n_cu);
   constexpr int B = STONK_EPI_BIAS, G = STONK_EPI_GELU, SV = STONK_EPI_SAVE_PREACT, GB = STONK_EPI_GELU_BWD,
-                R = STONK_EPI_RESID, D = STONK_EPI_DROPOUT;
-  const int epi = a.flags & (B | G | SV | GB | R | D);
+                R = STONK_EPI_RESID, D = STONK_EPI_DROPOUT, AG = STONK_EPI_AUX_GRAD;
+  const int epi = a.flags & (B | G | SV | GB | R | D | AG);
   if (out_mode == 1) return epi == 0 ? launch_w4<1, 0>(a, grid, st) : launch_w4<1, -1>(a, grid, st);
   if (out_mode == 2) return launch_w4<2, 0>(a, grid, st);
   switch (epi) {   // the combinations the STonKGs step uses are compiled with constant flags
@@ -510,6 +510,8 @@ int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, hipStream_t st) {
     case B | G: return launch_w4<0, B | G>(a, grid, st);
     case B | G | SV: return launch_w4<0, B | G | SV>(a, grid, st);
     case GB: return launch_w4<0, GB>(a, grid, st);
+    case B | G | SV | AG: return launch_w4<0, B | G | SV | AG>(a, grid, st);
+    case GB | AG: return launch_w4<0, GB | AG>(a, grid, st);
     case R: return launch_w4<0, R>(a, grid, st);
     case B | R: return launch_w4<0, B | R>(a, grid, st);
     case B | R | D: return launch_w4<0, B | R | D>(a, grid, st);

@@ -11,6 +11,9 @@
 #define STONK_EPI_SAVE_PREACT (1 << 5)  /* aux[m][n] (bf16) = value before the activation */
 #define STONK_EPI_GELU_BWD (1 << 6)     /* result *= gelu'(aux[m][n]) */
 #define STONK_EPI_DROPOUT (1 << 7)      /* inverted dropout (drop_p, seed) before the residual add */
+#define STONK_EPI_AUX_GRAD (1 << 8)     /* aux holds gelu'(pre-activation), not the pre-activation: SAVE_PREACT (with GELU) \
+                                           stores it, GELU_BWD multiplies by it - the erf/exp of the backward epilogue \
+                                           are paid once, in the forward one, which evaluates them anyway */
 #define STONK_EPI_DEBUG_REGSTAGE (1 << 16) /* A/B test: register staging instead of LDS-DMA (128x128 kernel) */
 #define STONK_EPI_DEBUG_V1 (1 << 17)       /* force the 128x128 two-barrier kernel */
 #define STONK_EPI_DEBUG_V2 (1 << 18)       /* force the persistent 256x256 kernel */

@@ -246,7 +246,7 @@ class Engine:
                  st1[1].data_ptr(), T, H, cfg.layer_norm_eps, 0, 0.0, 0, st)
         g = self.buf(f"{tag}.g", (T, I))
         u = self.buf(f"{tag}.u", (T, I)) if save is not None else None
-        fl = hip.EPI_BIAS | hip.EPI_GELU | (hip.EPI_SAVE_PREACT if save is not None else 0)
+        fl = hip.EPI_BIAS | hip.EPI_GELU | ((hip.EPI_SAVE_PREACT | hip.EPI_AUX_GRAD) if save is not None else 0)
         self.gemm(h1, w(prefix + ".intermediate.dense.weight"), g, T, I, H, flags=fl,
                   bias=f(prefix + ".intermediate.dense.bias"), aux=u)
         s2 = self.buf(f"{tag}.s2", (T, H))
@@ -291,7 +291,8 @@ class Engine:
         self.wgrad(df, sv["g"], g_(prefix + ".output.dense.weight"), g_(prefix + ".output.dense.bias"), H, I, T)
         du = self.buf(f"b.du.{par}", (T, I))
         self.gemm(df, wt[prefix + ".output.dense.weight"], du, T, I, H,
-                  flags=hip.EPI_GELU_BWD | (hip.EPI_DEBUG_V1 if self.comm_overlap else 0), aux=sv["u"])
+                  flags=hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD | (hip.EPI_DEBUG_V1 if self.comm_overlap else 0),
+                  aux=sv["u"])
         # ---- FFN up
         self.wgrad(du, sv["h1"], g_(prefix + ".intermediate.dense.weight"), g_(prefix + ".intermediate.dense.bias"), I, H,
                    T)

@@ -72,6 +72,21 @@ def test_gemm_epilogues(hip, dbg):
     uf = u.float().requires_grad_(True)
     (gp,) = torch.autograd.grad(torch.nn.functional.gelu(uf).sum(), uf)
     torch.testing.assert_close(out.float(), (A.float() @ B.float().t()) * gp, rtol=1e-2, atol=3e-2)
+    # the same pair with STONK_EPI_AUX_GRAD: forward leaves gelu'(pre-activation) in aux, backward multiplies by aux as is
+    aux2 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    out = _gemm(hip, A, B, flags=dbg | hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT | hip.EPI_AUX_GRAD, bias=bias,
+                aux=aux2)
+    pf = pre.clone().requires_grad_(True)
+    (gpre,) = torch.autograd.grad(torch.nn.functional.gelu(pf).sum(), pf)
+    torch.testing.assert_close(aux2.float(), gpre, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(out.float(), torch.nn.functional.gelu(pre), rtol=1e-2, atol=2e-2)
+    out = _gemm(hip, A, B, flags=dbg | hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD, aux=u)
+    torch.testing.assert_close(out.float(), (A.float() @ B.float().t()) * u.float(), rtol=1e-2, atol=3e-2)
+    # the modifier alone is refused
+    C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    rc = hip.lib().stonk_gemm_nt_bf16(hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, M, N, K, hip.EPI_AUX_GRAD, 0, 0, 0, 0,
+                                      0, 1.0, 1, 0, 0, 0.0, 0, hip.stream_ptr())
+    assert rc == -1
 
 
 @pytest.mark.parametrize("dbg,M,N,K,sk", [(1 << 17, 256, 128, 2048, 8), (1 << 18, 768, 768, 8192, 7),

@@ -31,7 +31,9 @@ extern "C" {
 int stonk_abi_version(void);
 
 /* C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T), A/B bf16, fp32 accumulate on MFMA. N % 128 == 0, K % 64 == 0.
- * `flags`: STONK_EPI_* (output type, bias, GELU, residual, saved pre-activation, GELU', dropout).
+ * `flags`: STONK_EPI_* (output type, bias, GELU, residual, saved pre-activation, GELU', dropout). STONK_EPI_AUX_GRAD
+ * modifies the two users of `aux`: SAVE_PREACT (next to GELU) then stores gelu'(pre-activation) and GELU_BWD multiplies
+ * by `aux` as is - the training step uses the pair, so the erf/exp of GELU' are evaluated once, in the forward epilogue.
  * m_dev / k_dev (nullable): effective M / K read from device memory at run time (label-sparse decoders).
  * Replaces torch addmm/mm of hf:models/bert/modeling_bert.py:154-156 (Q,K,V), :289-293 (attn out), :334-337
  * (FFN up + GELU), :347-351 (FFN down), :476-480 (head transform); ref:src/stonkgs/models/stonkgs_model.py:70-71

@@ -355,7 +355,7 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   // gradients overlapping on the second stream, 43.2 against 43.8 without the overlap): what it gains on its own
   // launches it takes from the overlapped weight-gradient kernels. Opt-in (STONK_W4=1 or the debug flag) until the
   // weight gradients run on the same schedule.
-  static const bool use_w4 = getenv("STONK_W4") != nullptr;
+  const bool use_w4 = getenv("STONK_W4") != nullptr;   // (read per call: tools/ab_step.py env:STONK_W4 toggles it in-process)
   if (w4_ok && ((w4_big && use_w4) || (flags & STONK_EPI_DEBUG_W4))) return stonk_gemm_w4_launch(a, out_mode, st);
   if (v2_ok && !(flags & (STONK_EPI_DEBUG_V1 | STONK_EPI_DEBUG_REGSTAGE)) && (big || (flags & STONK_EPI_DEBUG_V2)))
     return stonk_gemm256_launch(a, out_mode, st);

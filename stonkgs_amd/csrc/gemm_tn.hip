@@ -199,7 +199,8 @@ extern "C" int stonk_gemm_tn_bf16(const void* dY, int64_t lda, const void* X, in
   // gradients on 160 of the 256 CUs). split_k == -1 keeps the older eight-wave 256x256 TN form of gemm256.hip.
   if (split_k <= 0) {
     STONK_CHECK_ARG(M >= 256 && N >= 256, STONK_ESHAPE);
-    STONK_CHECK_ARG(lda % 64 == 0 && ldb % 64 == 0 && (long)K * lda < (1L << 30) && (long)K * ldb < (1L << 30), STONK_ESHAPE);
+    // (operands are addressed per 64-token K tile: 64 rows of either operand must stay inside 32-bit byte offsets)
+    STONK_CHECK_ARG(lda % 64 == 0 && ldb % 64 == 0 && lda < (1L << 23) && ldb < (1L << 23), STONK_ESHAPE);
     STONK_CHECK_ARG(split_k >= -1024, STONK_ESHAPE);
     stonk_gemm::GemmArgs g = {};
     g.A = (const bf16*)dY; g.B = (const bf16*)X; g.C = dW; g.bias = dbias; g.k_dev = k_dev;

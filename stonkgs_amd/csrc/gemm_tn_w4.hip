@@ -112,17 +112,36 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const GemmArgs p) {
   const int voffA = (lane >> 2) * lda2 + wave * 128 + (lane & 3) * 16;
   const int voffB = (lane >> 2) * ldb2 + wave * 128 + (lane & 3) * 16;
   const int pstepA = 16 * lda2, pstepB = 16 * ldb2;
-  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, Kact * lda2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, Kact * ldb2, 0x00020000);
+  // The buffer resources are re-based on the first token of every K tile (64-bit scalar adds), so operand extents beyond
+  // 4 GB work - the entity decoder's dlogits are [16 384 x 175 104] bf16 = 5.7 GB - and `num_records` = the bytes from
+  // there to the end of the live tokens (clamped to 32 bits; a K tile spans 64 rows, far less than the clamp).
+  const bf16* curA = p.A;
+  const bf16* curB = p.B;
+  unsigned recA = 0, recB = 0;
+  long ptok = 0;              // first token of the K tile the prefetch cursor points at
+  int soffA = 0, soffB = 0;   // tile column, bytes
+  auto set_cursor = [&]() {
+    curA = p.A + ptok * p.lda;
+    curB = p.B + ptok * p.ldb;
+    const long left = (long)Kact - ptok;
+    long ra = left * lda2, rb = left * ldb2;
+    ra = ra < 0 ? 0 : (ra > 0xFFFFF000L ? 0xFFFFF000L : ra);
+    rb = rb < 0 ? 0 : (rb > 0xFFFFF000L ? 0xFFFFF000L : rb);
+    recA = (unsigned)ra;
+    recB = (unsigned)rb;
+  };
   const int wofs = wave * 8192 + lane * 16;   // sub-tile pair of this wave: 2 x 4 KiB
-  int soffA = 0, soffB = 0;
   auto set_sources = [&](const Work& w) {
-    soffA = (int)w.k_begin * lda2 + w.m0 * 2;
-    soffB = (int)w.k_begin * ldb2 + w.n0 * 2;
+    ptok = w.k_begin;
+    soffA = w.m0 * 2;
+    soffB = w.n0 * 2;
+    set_cursor();
   };
   auto load_piece = [&](const int q, bf16x8& d) {
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     const int qq = q & 7;
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)curA, 0, recA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)curB, 0, recB, 0x00020000);
     const u32x4 v = (q < 8) ? __builtin_amdgcn_raw_buffer_load_b128(rsrcA, voffA, soffA + (qq >> 1) * pstepA + (qq & 1) * 64, 0)
                             : __builtin_amdgcn_raw_buffer_load_b128(rsrcB, voffB, soffB + (qq >> 1) * pstepB + (qq & 1) * 64, 0);
     d = __builtin_bit_cast(bf16x8, v);
@@ -186,8 +205,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(const GemmArgs p) {
     if (!p_valid) return;   // out of work: the cursor keeps re-reading its last K tile (never consumed)
     if (pk + 1 < pw.nk) {
       ++pk;
-      soffA += BK * lda2;
-      soffB += BK * ldb2;
+      ptok += BK;
+      set_cursor();
       return;
     }
     Work nw;

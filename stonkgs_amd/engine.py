@@ -155,10 +155,12 @@ class Engine:
         # is fastest when tiles x split fills ONE co-resident wave without a tail (432-480 workgroups)
         tiles = ((M + 127) // 128) * (N // 128)
         # the large weight gradients (FFN up / down, fused QKV) go to the four-wave 256x256 kernel, which splits K itself
-        # (split_k = 0): -1.4 ms per step in an interleaved A/B; 768 x 768 (36 tiles) and the label-sparse decoder
-        # gradients (device-side token counts, wide strides) stay on the 128x128 kernel. Beside the dgrad chain (second
+        # (split_k = 0): -1.4 ms per step in an interleaved A/B; 768 x 768 (36 tiles) and the text decoder's
+        # gradient (29 056 rows: not a multiple of 256) stay on the 128x128 kernel. Beside the dgrad chain (second
         # stream) the kernel is held to 160 CUs' worth of workgroups (split_k = -160): another -1.5 ms
-        if tiles >= 100 and K >= 16384 and M % 256 == 0 and N % 256 == 0 and M <= 4096 and not os.environ.get("STONK_TN_V1"):
+        # ... and so does the entity decoder's 175 104 x 768 gradient (2052 unsplit tiles, device-side token count, 5.7 GB
+        # operand extent - the kernel re-bases its buffer resources per K tile): 863 us against 966 alone, -0.27 ms in the step
+        if tiles >= 100 and K >= 16384 and M % 256 == 0 and N % 256 == 0 and not os.environ.get("STONK_TN_V1"):
             return -int(os.environ.get("STONK_TN_CUS", "160")) if side_stream else 0
         return max(1, min(32, 480 // tiles, K // 64))
 

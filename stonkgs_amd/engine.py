@@ -78,6 +78,7 @@ class Engine:
         # would wait for them (its late workgroups own a share of the tiles). Backward's only such launch on the main
         # stream (dgrad through GELU) then takes the 128x128 kernel, whose grid the hardware schedules dynamically.
         self.comm_overlap = False
+        self.decoder_dgrad_256 = True
         self._wstream: Optional[torch.cuda.Stream] = None
         # The optimizer (grad-norm, AdamW, W^T refresh: ~2 ms of HBM-bound work) runs on a third stream; the next step's
         # frozen-backbone forward reads none of what it writes and starts beside it. `wait_params()` orders the current
@@ -512,8 +513,14 @@ class Engine:
             # few output tiles (count/128 x H/128), very long contraction (the vocabulary): split-K into fp32
             dhs = self.buf("b.dhs32", (cap, H), F32)
             dhs.zero_()
-            self.gemm(h["dl"], wt[wname], dhs, cap, H, npad, flags=hip.EPI_OUT_F32_ATOMIC,
-                      split_k=max(1, min(16, npad // 2048)), m_dev=h["cnt"], alpha=gscale)
+            # the persistent 256x256 kernel with 8 splits (<= 30 live tiles x 8 = one round of the CUs) against 128x128
+            # tiles with 16: 734 us against 951 for the entity decoder (tools/bench_decoder_dgrad.py)
+            if self.decoder_dgrad_256 and npad >= 16384 and cap >= 1024 and H % 256 == 0:
+                self.gemm(h["dl"], wt[wname], dhs, cap, H, npad, flags=hip.EPI_OUT_F32_ATOMIC | hip.EPI_DEBUG_V2,
+                          split_k=8, m_dev=h["cnt"], alpha=gscale)
+            else:
+                self.gemm(h["dl"], wt[wname], dhs, cap, H, npad, flags=hip.EPI_OUT_F32_ATOMIC,
+                          split_k=max(1, min(16, npad // 2048)), m_dev=h["cnt"], alpha=gscale)
             hip.call("stonk_scatter_rows_f32_to_bf16", dhs.data_ptr(), H, h["rows"].data_ptr(), h["cnt"].data_ptr(),
                      dt.data_ptr(), H, H, st)
             self.wgrad(h["dl"], h["hs"], g_(wname, padded=True), None, npad, H, cap, k_dev=h["cnt"], alpha=gscale)

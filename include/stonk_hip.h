@@ -148,6 +148,12 @@ int stonk_scatter_rows_f32_to_bf16(const float* src, int64_t ld_src, const int* 
 int stonk_softmax_xent_fwd_bwd(const float* logits, int64_t ld, int ncols, int npad, const int* targets,
                                const int* count_dev, float* loss_sum, void* dlogits, int64_t ld_d, float grad_scale,
                                int cap_rows, int* err_flag, void* stream);
+
+/* The same on fp16 logits (stonk_gemm_nt_bf16 with STONK_EPI_OUT_F16): 6 bytes of HBM traffic per logit instead of 10 -
+ * the training step's label-sparse decoders use this pair; all arithmetic stays fp32. ld % 8 == 0. */
+int stonk_softmax_xent_f16_fwd_bwd(const void* logits_f16, int64_t ld, int ncols, int npad, const int* targets,
+                                   const int* count_dev, float* loss_sum, void* dlogits, int64_t ld_d, float grad_scale,
+                                   int cap_rows, int* err_flag, void* stream);
 /* NSP loss (ref:stonkgs_model.py:241-243): loss_sum_cnt[0] += sum, [1] += number of labels. */
 int stonk_nsp_xent_fwd_bwd(const float* logits, const int64_t* labels, int B, int C, float* loss_sum_cnt, float* dlogits,
                            float grad_scale, int* err_flag, void* stream);

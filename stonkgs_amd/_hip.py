@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libstonk_hip.so")
 EPI_OUT_BF16 = 0
 EPI_OUT_F32 = 1
 EPI_OUT_F32_ATOMIC = 2
+EPI_OUT_F16 = 3
 EPI_BIAS = 1 << 2
 EPI_GELU = 1 << 3
 EPI_RESID = 1 << 4
@@ -60,6 +61,7 @@ _SIGNATURES = {
     "stonk_scatter_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp],
     "stonk_scatter_rows_f32_to_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp],
     "stonk_softmax_xent_fwd_bwd": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _f32, _i32, _vp, _vp],
+    "stonk_softmax_xent_f16_fwd_bwd": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _f32, _i32, _vp, _vp],
     "stonk_nsp_xent_fwd_bwd": [_vp, _vp, _i32, _i32, _vp, _vp, _f32, _vp, _vp],
     "stonk_loss_finalize": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "stonk_small_linear_fwd": [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],

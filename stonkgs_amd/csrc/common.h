@@ -8,6 +8,8 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -29,6 +31,9 @@ static inline int stonk_launch_status() {
 }
 
 #define WAVE 64
+
+// fp32 -> fp16 with the range clamped (STONK_EPI_OUT_F16: an overflowing logit must not become an infinity)
+__device__ __forceinline__ _Float16 to_f16_sat(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -372,6 +372,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
               *(bf16x8*)((bf16*)p.C + (long)mm * p.ldc + n) = o;
+            } else if (OUT_MODE == 3) {
+              f16x8 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = to_f16_sat(v[e]);
+              *(f16x8*)((_Float16*)p.C + (long)mm * p.ldc + n) = o;
             } else {
               float* dst = (float*)p.C + (long)mm * p.ldc + n;
               *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
@@ -432,7 +437,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // waits for the next K tile to land, and only then (E3) issues the stores. The two K tiles after a boundary use
   // waits whose counts skip over the S stores (`mode` 1: no issue, one wait; `mode` 2: normal issue, waits +S); the
   // first wait that has to see the stores retired comes 7 phases after they were issued.
-  const int S = (OUT_MODE == 0) ? (((EPI >= 0 ? EPI : p.flags) & STONK_EPI_SAVE_PREACT) ? 32 : 16) : (OUT_MODE == 1 ? 32 : 0);
+  const int S = (OUT_MODE == 0) ? (((EPI >= 0 ? EPI : p.flags) & STONK_EPI_SAVE_PREACT) ? 32 : 16)
+                                : (OUT_MODE == 1 ? 32 : (OUT_MODE == 3 ? 16 : 0));
   auto wait_keep = [&](bool plus4) {   // at most S (+4) youngest operations may stay outstanding
     if (S == 16) { if (plus4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
     else if (S == 32) { if (plus4) asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }
@@ -586,6 +592,7 @@ int stonk_gemm256_launch(const GemmArgs& a, int out_mode, hipStream_t st) {
   const int epi = a.flags & (B | G | SV | GB | R | D | AG);
   if (out_mode == 1) return epi == 0 ? launch256<1, 0>(a, grid, st) : launch256<1, -1>(a, grid, st);
   if (out_mode == 2) return launch256<2, 0>(a, grid, st);
+  if (out_mode == 3) return launch256<3, 0>(a, grid, st);
   switch (epi) {   // the combinations the STonKGs step uses are compiled with constant flags
     case 0: return launch256<0, 0>(a, grid, st);
     case B: return launch256<0, B>(a, grid, st);

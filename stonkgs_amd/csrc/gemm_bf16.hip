@@ -250,6 +250,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
           if (OUT_MODE == 0) {
             bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
             *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+          } else if (OUT_MODE == 3) {
+            f16x4 o = {to_f16_sat(v[0]), to_f16_sat(v[1]), to_f16_sat(v[2]), to_f16_sat(v[3])};
+            *(f16x4*)((_Float16*)p.C + (long)m * p.ldc + n) = o;
           } else {
             *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
           }
@@ -267,6 +270,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
           if (OUT_MODE == 0) {
             bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
             *(bf16x4*)((bf16*)p.C + (long)m * p.ldc + n) = o;
+          } else if (OUT_MODE == 3) {
+            f16x4 o = {to_f16_sat(v[0]), to_f16_sat(v[1]), to_f16_sat(v[2]), to_f16_sat(v[3])};
+            *(f16x4*)((_Float16*)p.C + (long)m * p.ldc + n) = o;
           } else {
             *(f32x4*)((float*)p.C + (long)m * p.ldc + n) = v;
           }
@@ -301,7 +307,8 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   STONK_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, STONK_EALIGN);
   STONK_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), STONK_EALIGN);
   const int out_mode = flags & STONK_EPI_OUT_MASK;
-  STONK_CHECK_ARG(out_mode <= 2, STONK_EINVAL);
+  if (out_mode == STONK_EPI_OUT_F16)   // plain conversion of the product: no other epilogue, no split
+    STONK_CHECK_ARG((flags & 0x1FC) == 0 && split_k == 1, STONK_EINVAL);
   STONK_CHECK_ARG(split_k == 1 || out_mode == STONK_EPI_OUT_F32_ATOMIC, STONK_EINVAL);
   if (flags & STONK_EPI_BIAS) STONK_CHECK_ARG(bias && ((uintptr_t)bias % 16 == 0), STONK_EINVAL);
   if (flags & STONK_EPI_RESID) STONK_CHECK_ARG(resid && ldr % 4 == 0, STONK_EINVAL);
@@ -338,7 +345,7 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
                       (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0));
   // the four-wave kernel walks K tiles in pairs: an even number per work item
   // ... and addresses its operands with 32-bit byte offsets from a per-K-tile base, chunk-swizzled by XOR (ld % 64)
-  const bool w4_ok = ldc % 8 == 0 && !both_sides && (K / BK) % (2 * split_k) == 0 && !k_dev && lda % 64 == 0 &&
+  const bool w4_ok = ldc % 8 == 0 && !both_sides && out_mode != STONK_EPI_OUT_F16 && (K / BK) % (2 * split_k) == 0 && !k_dev && lda % 64 == 0 &&
                      ldb % 64 == 0 && (long)M * lda < (1L << 30) && (long)N * ldb < (1L << 30) && (long)M * ldc * (out_mode == 0 ? 2 : 4) < (1L << 31) &&
                      (!(flags & STONK_EPI_RESID) || (ldr % 8 == 0 && (uintptr_t)resid % 16 == 0)) &&
                      (!(flags & (STONK_EPI_SAVE_PREACT | STONK_EPI_GELU_BWD)) ||
@@ -371,10 +378,12 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
     switch (out_mode) {
       case STONK_EPI_OUT_BF16: return launch<0, false, -1>(a, grid, st);
       case STONK_EPI_OUT_F32: return launch<1, false, -1>(a, grid, st);
+      case STONK_EPI_OUT_F16: return launch<3, false, -1>(a, grid, st);
       default: return launch<2, false, -1>(a, grid, st);
     }
   }
   if (out_mode == STONK_EPI_OUT_F32_ATOMIC) return launch<2, true, -1>(a, grid, st);
+  if (out_mode == STONK_EPI_OUT_F16) return launch<3, true, 0>(a, grid, st);
   if (out_mode == STONK_EPI_OUT_F32) return epi == 0 ? launch<1, true, 0>(a, grid, st) : launch<1, true, -1>(a, grid, st);
   switch (epi) {
     case 0: return launch<0, true, 0>(a, grid, st);

@@ -101,9 +101,27 @@ __global__ __launch_bounds__(256) void scatter_rows_f32_kernel(const float* __re
   }
 }
 
-// One block per labelled row: online (max, sum-exp) sweep of the fp32 logits, then a second sweep writes
-// dlogits = (softmax - onehot) * gscale / count as bf16 (columns [ncols, npad) = 0). loss_sum += lse - x[target].
-__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits, long ld, int ncols, int npad,
+// One block per labelled row: online (max, sum-exp) sweep of the logits (fp32, or the fp16 the decoder GEMM can leave:
+// LT), then a second sweep writes dlogits = (softmax - onehot) * gscale / count as bf16 (columns [ncols, npad) = 0).
+// loss_sum += lse - x[target]. All arithmetic in fp32. HBM-bound: 10 bytes per logit with fp32 logits, 6 with fp16.
+template <typename LT> struct LogitVec;
+template <> struct LogitVec<float> {
+  static __device__ __forceinline__ void load8(const float* x, float (&v)[8]) {
+    const f32x4 a = *(const f32x4*)x, b = *(const f32x4*)(x + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+  }
+};
+template <> struct LogitVec<_Float16> {
+  static __device__ __forceinline__ void load8(const _Float16* x, float (&v)[8]) {
+    const f16x8 a = *(const f16x8*)x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
+  }
+};
+
+template <typename LT>
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const LT* __restrict__ logits, long ld, int ncols, int npad,
                                                            const int* __restrict__ targets, const int* __restrict__ count,
                                                            float* __restrict__ loss_sum, bf16* __restrict__ dlogits,
                                                            long ld_d, float gscale, int* __restrict__ err,
@@ -113,20 +131,22 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const float g = gscale / (float)cnt;
   for (int row = blockIdx.x; row < cnt; row += gridDim.x) {
-    const float* x = logits + (long)row * ld;
+    const LT* x = logits + (long)row * ld;
     float m = -3.0e38f, s = 0.f;
-    const int n4 = ncols >> 2;
-    for (int i = t; i < n4; i += 256) {
-      const f32x4 v = *(const f32x4*)(x + 4 * i);
-      const float vm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    const int n8 = ncols >> 3;
+    for (int i = t; i < n8; i += 256) {
+      float v[8];
+      LogitVec<LT>::load8(x + 8 * i, v);
+      const float vm = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
       if (vm > m) {
         s *= __expf(m - vm);
         m = vm;
       }
-      s += __expf(v[0] - m) + __expf(v[1] - m) + __expf(v[2] - m) + __expf(v[3] - m);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += __expf(v[j] - m);
     }
-    for (int i = (n4 << 2) + t; i < ncols; i += 256) {
-      const float v = x[i];
+    for (int i = (n8 << 3) + t; i < ncols; i += 256) {
+      const float v = (float)x[i];
       if (v > m) {
         s *= __expf(m - v);
         m = v;
@@ -156,7 +176,7 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
       if (t == 0) atomicOr(err, 8);
       tgt = 0;
     }
-    if (t == 0) atomicAdd(loss_sum, lse - x[tgt]);
+    if (t == 0) atomicAdd(loss_sum, lse - (float)x[tgt]);
     if (dlogits) {
       bf16* d = dlogits + (long)row * ld_d;
       const int p8 = npad >> 3;
@@ -164,11 +184,11 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
         const int c0 = i * 8;
         bf16x8 o;
         if (c0 + 8 <= ncols) {
-          const f32x4 a = *(const f32x4*)(x + c0), b = *(const f32x4*)(x + c0 + 4);
+          float v[8];
+          LogitVec<LT>::load8(x + c0, v);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float v = j < 4 ? a[j] : b[j - 4];
-            float pr = __expf(v - lse);
+            float pr = __expf(v[j] - lse);
             if (c0 + j == tgt) pr -= 1.f;
             o[j] = (bf16)(pr * g);
           }
@@ -177,7 +197,7 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
           for (int j = 0; j < 8; ++j) {
             float pr = 0.f;
             if (c0 + j < ncols) {
-              pr = __expf(x[c0 + j] - lse);
+              pr = __expf((float)x[c0 + j] - lse);
               if (c0 + j == tgt) pr -= 1.f;
             }
             o[j] = (bf16)(pr * g);
@@ -289,8 +309,21 @@ extern "C" int stonk_softmax_xent_fwd_bwd(const float* logits, int64_t ld, int n
   STONK_CHECK_ARG(logits && targets && count_dev && loss_sum && err_flag && cap_rows >= 0, STONK_EINVAL);
   STONK_CHECK_ARG(ncols > 0 && npad >= ncols && npad % 8 == 0 && ld >= npad && ld % 4 == 0, STONK_ESHAPE);
   STONK_CHECK_ARG(!dlogits || (ld_d >= npad && ld_d % 8 == 0), STONK_ESHAPE);
-  hipLaunchKernelGGL(softmax_xent_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, ncols, npad,
-                     targets, count_dev, loss_sum, (bf16*)dlogits, (long)ld_d, grad_scale, err_flag, cap_rows);
+  hipLaunchKernelGGL(softmax_xent_kernel<float>, dim3(2048), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, ncols,
+                     npad, targets, count_dev, loss_sum, (bf16*)dlogits, (long)ld_d, grad_scale, err_flag, cap_rows);
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_softmax_xent_f16_fwd_bwd(const void* logits_f16, int64_t ld, int ncols, int npad, const int* targets,
+                                              const int* count_dev, float* loss_sum, void* dlogits, int64_t ld_d,
+                                              float grad_scale, int cap_rows, int* err_flag, void* stream) {
+  STONK_CHECK_ARG(logits_f16 && targets && count_dev && loss_sum && err_flag && cap_rows >= 0, STONK_EINVAL);
+  STONK_CHECK_ARG(ncols > 0 && npad >= ncols && npad % 8 == 0 && ld >= npad && ld % 8 == 0, STONK_ESHAPE);
+  STONK_CHECK_ARG(!dlogits || (ld_d >= npad && ld_d % 8 == 0), STONK_ESHAPE);
+  STONK_CHECK_ARG((uintptr_t)logits_f16 % 16 == 0, STONK_EALIGN);
+  hipLaunchKernelGGL(softmax_xent_kernel<_Float16>, dim3(2048), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)logits_f16, (long)ld, ncols, npad, targets, count_dev, loss_sum, (bf16*)dlogits,
+                     (long)ld_d, grad_scale, err_flag, cap_rows);
   return stonk_launch_status();
 }
 

@@ -4,6 +4,9 @@
 #define STONK_EPI_OUT_BF16 0        /* C is bf16 */
 #define STONK_EPI_OUT_F32 1         /* C is fp32 */
 #define STONK_EPI_OUT_F32_ATOMIC 2  /* C (fp32) += result, via global_atomic_add_f32; required for split_k > 1 */
+#define STONK_EPI_OUT_F16 3         /* C is IEEE fp16, clamped to +-65504 (label-sparse decoder logits: fp32's range is not
+                                       needed, and 11 significant bits against bf16's 8 keep softmax terms to 0.05 %);
+                                       no other epilogue flag */
 #define STONK_EPI_OUT_MASK 3
 #define STONK_EPI_BIAS (1 << 2)         /* + bias[n] (fp32) */
 #define STONK_EPI_GELU (1 << 3)         /* exact erf GELU */

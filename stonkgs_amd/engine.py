@@ -79,6 +79,7 @@ class Engine:
         # stream (dgrad through GELU) then takes the 128x128 kernel, whose grid the hardware schedules dynamically.
         self.comm_overlap = False
         self.decoder_dgrad_256 = True
+        self.f16_logits = True      # label-sparse decoder logits in fp16 (False: fp32, 4 more bytes of HBM traffic per logit)
         self._wstream: Optional[torch.cuda.Stream] = None
         # The optimizer (grad-norm, AdamW, W^T refresh: ~2 ms of HBM-bound work) runs on a third stream; the next step's
         # frozen-backbone forward reads none of what it writes and starts beside it. `wait_params()` orders the current
@@ -451,11 +452,15 @@ class Engine:
                 hs = self.buf(f"l.{nm}.hs", (cap, H))
                 hip.call("stonk_gather_rows_bf16", t.data_ptr(), H, rows.data_ptr(), cnt.data_ptr(), hs.data_ptr(), H, H,
                          cap, st)
-                logits = self.buf(f"l.{nm}.logits", (cap, npad), F32)
-                self.gemm(hs, w(wname), logits, cap, npad, H, flags=hip.EPI_OUT_F32, m_dev=cnt)
+                # logits of the labelled rows only, in fp16 (11 significant bits; the softmax arithmetic stays fp32): the
+                # decoder GEMM writes and the cross-entropy reads 2 bytes per logit instead of 4 - both are HBM-bound on them
+                f16 = self.f16_logits
+                logits = self.buf(f"l.{nm}.logits", (cap, npad), torch.float16 if f16 else F32)
+                self.gemm(hs, w(wname), logits, cap, npad, H, flags=hip.EPI_OUT_F16 if f16 else hip.EPI_OUT_F32, m_dev=cnt)
                 dl = self.buf(f"l.{nm}.dl", (cap, npad)) if need_backward else None
-                hip.call("stonk_softmax_xent_fwd_bwd", logits.data_ptr(), npad, N, npad, tg.data_ptr(), cnt.data_ptr(),
-                         acc[hi:hi + 1].data_ptr(), hip.ptr(dl), npad, 1.0, cap, self.err.data_ptr(), st)
+                hip.call("stonk_softmax_xent_f16_fwd_bwd" if f16 else "stonk_softmax_xent_fwd_bwd", logits.data_ptr(), npad,
+                         N, npad, tg.data_ptr(), cnt.data_ptr(), acc[hi:hi + 1].data_ptr(), hip.ptr(dl), npad, 1.0, cap,
+                         self.err.data_ptr(), st)
                 save[nm] = dict(rows=rows, cnt=cnt, hs=hs, dl=dl)
             dnsp = self.buf("l.dnsp", (B, 2), F32) if need_backward else None
             hip.call("stonk_nsp_xent_fwd_bwd", nsp.data_ptr(), nsp_labels.data_ptr(), B, 2, acc[2:4].data_ptr(),

@@ -40,6 +40,23 @@ def test_gemm_plain_bf16_and_f32(hip, M, N, K, kernel):
     assert err <= 1e-3 * math.sqrt(K), f"fp32-out max err {err}"
     out16 = _gemm(hip, A, B, torch.bfloat16, flags=hip.EPI_OUT_BF16 | dbg)
     torch.testing.assert_close(out16.float(), ref, rtol=1.6e-2, atol=1e-2 * math.sqrt(K) / 8)
+    if kernel in ("v1", "v2_256", "auto"):   # fp16 output (label-sparse logits): the fp32 result rounded once, to 11 bits
+        outh = _gemm(hip, A, B, torch.float16, flags=hip.EPI_OUT_F16 | dbg)
+        torch.testing.assert_close(outh.float(), out32.half().float(), rtol=1e-3, atol=1e-3)
+
+
+def test_gemm_f16_output_saturates_and_takes_no_epilogue(hip):
+    A = torch.full((128, 64), 200.0, device="cuda", dtype=torch.bfloat16)
+    B = torch.full((128, 64), 200.0, device="cuda", dtype=torch.bfloat16)
+    B[1] = -200.0
+    out = _gemm(hip, A, B, torch.float16, flags=hip.EPI_OUT_F16)   # 64 * 200 * 200 = 2.56e6 > 65504
+    assert torch.isfinite(out).all() and float(out[0, 0]) == 65504.0 and float(out[0, 1]) == -65504.0
+    C = torch.empty(128, 128, device="cuda", dtype=torch.float16)
+    bias = torch.zeros(128, device="cuda")
+    rc = hip.lib().stonk_gemm_nt_bf16(hip.ptr(A), 64, hip.ptr(B), 64, hip.ptr(C), 128, 128, 128, 64,
+                                      hip.EPI_OUT_F16 | hip.EPI_BIAS, hip.ptr(bias), 0, 0, 0, 0, 1.0, 1, 0, 0, 0.0, 0,
+                                      hip.stream_ptr())
+    assert rc == -1
 
 
 def test_gemm_asymmetric_identity(hip):

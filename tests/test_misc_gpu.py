@@ -104,6 +104,19 @@ def test_softmax_xent(hip, N):
     torch.testing.assert_close(dl[:R, :N].float(), x.grad, rtol=1e-2, atol=1e-5)
     assert (dl[:R, N:] == 0).all()
     assert err.item() == 0
+    # the fp16-logit entry point: same numbers as the fp32 one fed the rounded logits
+    lh = logits.half()
+    loss_h = torch.zeros(1, device="cuda")
+    dl_h = torch.full((cap, npad), 5.0, device="cuda", dtype=torch.bfloat16)
+    hip.call("stonk_softmax_xent_f16_fwd_bwd", hip.ptr(lh), npad, N, npad, hip.ptr(tg), hip.ptr(cnt), hip.ptr(loss_h),
+             hip.ptr(dl_h), npad, 1.0, cap, hip.ptr(err), hip.stream_ptr())
+    xh = lh[:R, :N].float().requires_grad_(True)
+    ref_h = F.cross_entropy(xh, tg[:R].long())
+    ref_h.backward()
+    torch.testing.assert_close(loss_h[0] / R, ref_h, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dl_h[:R, :N].float(), xh.grad, rtol=1e-2, atol=1e-5)
+    assert (dl_h[R:64] == 0).all() and (dl_h[64:] == 5.0).all() and (dl_h[:R, N:] == 0).all()
+    assert abs(float(loss_h[0] - loss[0])) / R < 2e-3   # and close to the fp32-logit loss
 
 
 def test_nsp_and_finalize(hip):

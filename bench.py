@@ -24,9 +24,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# gemm_tn_w4_kernel, average of its 36 launches per step: 303.8 MB fetched (FETCH_SIZE doubled, the gfx950 correction of
-# MI355X_MICROARCH.md) + 45.0 MB of float atomics written (profiles/r01_final_pmc_traffic.csv)
-TN_W4_TRAFFIC_BYTES = 348.8e6
+# gemm_tn_w4_kernel, average of its 37 launches per step: 337.7 MB fetched (FETCH_SIZE doubled, the gfx950 correction of
+# MI355X_MICROARCH.md) + 61.1 MB of float atomics written (profiles/r01_final_pmc_traffic.csv)
+TN_W4_TRAFFIC_BYTES = 398.8e6
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
 # algorithmic GFLOP per text-triple pair, 12L/768/S=512, label-sparse decoders
 GFLOP_PER_PAIR_STEP = 373.4
@@ -153,8 +153,8 @@ def main():
     roofline = None
     gemm_all = None
     if not args.no_roofline:
-        # dominant kernel of the step = gemm_tn_w4_kernel (weight + bias gradients of the FFN and fused-QKV linears, 36
-        # launches/step; profiles/ has the rocprofv3 kernel-trace of the same command): per-launch HIP events on the
+        # dominant kernel of the step = gemm_tn_w4_kernel (weight + bias gradients of the FFN and fused-QKV linears and the
+        # entity decoder's weight gradient, 37 launches/step; profiles/ has the rocprofv3 kernel-trace of the same command): per-launch HIP events on the
         # launch stream over two extra steps; achieved = algorithmic FLOPs (2 * M' * N' * tokens per launch) / summed
         # durations
         # (every rank runs the two steps - they contain the gradient all-reduce - and times its own launches; rank 0 reports)
@@ -174,7 +174,7 @@ def main():
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": TN_W4_TRAFFIC_BYTES,
                     "traffic_note": "bytes per launch at the L2's memory side = 2 x FETCH_SIZE + WRITE_SIZE (KiB, separate "
                                     "rocprofv3 --pmc passes over this command, profiles/r01_final_pmc_traffic.csv) against "
-                                    "234 MB of operands + 9.4 MB of output per launch; a recorded constant - counters "
+                                    "274 MB of operands + output per launch (36 encoder launches of 243 MB, the entity decoder's 1.39 GB); a recorded constant - counters "
                                     "cannot be read from inside the bench",
                     "launches_per_step": s["launches"] // 2,
                     "avg_launch_us": round(s["seconds"] / s["launches"] * 1e6, 1),

@@ -1,0 +1,77 @@
+"""Rewrite the "Headline" and "Where the step goes" sections of profiles/README.md from the committed artefacts
+(r01_final_bench.json, r01_final_kernel_stats.csv, r01_final_pmc_traffic.csv), so the prose cannot drift from the files.
+
+  python tools/update_profiles_readme.py [steps_in_the_rocprof_run=9]"""
+import csv
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+    d = json.load(open(os.path.join(P, "r01_final_bench.json")))
+    rows = list(csv.DictReader(open(os.path.join(P, "r01_final_kernel_stats.csv"))))
+    pmc = list(csv.DictReader(open(os.path.join(P, "r01_final_pmc_traffic.csv"))))
+    tn = next(r for r in pmc if r["kernel"].startswith("gemm_tn_w4"))
+    total_gb = float(next(r for r in pmc if r["kernel"] == "TOTAL")["GB_per_step"])
+    rf, ag, cb = d["roofline"], d["all_gemm"], d["cpu_baseline"]
+    head = f"""## Headline (r01_final_bench.json)
+
+* **{d["value"]:.0f} text-triple pairs/s on one MI355X, {d["ms_per_step"]:.1f} ms per training step** at BASELINE config 2 (12L/768h, V = 28 996,
+  K = 175 094, batch 64, seq 256 + 256, dropout 0.1 live, full step incl. frozen backbone, both decoders, 3 x CE, backward,
+  clip, AdamW). First run of the round: 1103 pairs/s (58.0 ms); middle of the round 1361 (47.0 ms). Box-to-box spread is
+  large (one commit read 38.9, 39.3 and 42.7 ms on three boxes); A/B comparisons in this repository are interleaved
+  inside one process (`tools/ab_step.py`).
+* whole step: 373.4 GFLOP/pair x {d["value"]:.0f} pairs/s = {d["value"] * 373.4 / 1e3:.0f} TFLOP/s = **{d["step_mfma_frac"] * 100:.1f} % of the 2.5 PFLOP/s dense-bf16 peak**
+  (`step_mfma_frac`); all GEMM launches together: {ag["achieved_tflops"]:.0f} TFLOP/s = {ag["frac"] * 100:.1f} %; the dominant kernel
+  (`gemm_tn_w4_kernel`, {rf["launches_per_step"]} launches/step): {rf["achieved"]:.0f} TFLOP/s = {rf["frac"] * 100:.1f} % (`roofline`; HIP events around each
+  launch on the stream it is launched on - in the step it shares the chip with the dgrad chain on the main stream, which
+  is why its average in the rocprofv3 table below is longer than the {rf["avg_launch_us"]:.0f} us it needs alone).
+* fabric traffic (`r01_final_pmc_traffic.csv`: FETCH_SIZE and WRITE_SIZE in separate `--pmc` passes, FETCH doubled as the
+  guide prescribes for gfx950): {total_gb:.0f} GB per step; `gemm_tn_w4_kernel` {float(tn["fetch_corrected_MB_per_launch"]):.0f} MB read + {float(tn["write_MB_per_launch"]):.0f} MB of float atomics per
+  launch against 274 MB of operands and output (36 encoder launches of 243 MB, the entity decoder's 1.39 GB).
+  `r01_c_pmc_traffic_before_xcd_mapping.csv` is the same measurement earlier in the round (131 GB/step): attention
+  forward read 455 MB per launch for 151 MB of Q/K/V (the four 128-row blocks of a head sat on four XCDs), the entity
+  decoder 3.8 GB for a 269 MB weight, and stand-alone (252 or 243 workgroups, not a multiple of 8) the weight-gradient
+  kernel 866 MB for 201 MB - all three were work->XCD mapping mistakes, now fixed.
+* CPU baseline (`cpu_baseline`, the oracle = CPU restatement of the reference's HuggingFace path, fp32, same model shape,
+  batch 2, {cb["cores"]} host threads of the GPU box): **{cb["value"]:.2f} pairs/s**. GPU/CPU = {d["value"] / cb["value"]:.0f} (a reported baseline, not a target).
+* The clock: under MFMA load the chip runs at 1.5-1.9 GHz, not 2.4 (SQ_BUSY_CYCLES / wall time in the PMC file above), so
+  even a pure-MFMA loop tops out near 1.7 PFLOP/s here and the vendor library's best GEMM at 1.56; every fraction in this
+  repository is nevertheless quoted against the 2.5 PFLOP/s nominal peak.
+
+"""
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    tbl = "## Where the step goes (r01_final_kernel_stats.csv, per step)\n\n"
+    tbl += "| kernel | launches/step | avg us | ms/step | % of GPU time |\n|---|---|---|---|---|\n"
+    for r in rows[:26]:
+        n = re.sub(r"\(anonymous namespace\)::", "", r["Name"]).split("(")[0].replace("void ", "")[:64]
+        tbl += (f"| `{n}` | {int(r['Calls']) / steps:.1f} | {float(r['AverageNs']) / 1e3:.1f} | "
+                f"{float(r['TotalDurationNs']) / steps / 1e6:.3f} | {float(r['Percentage']):.1f} |\n")
+    lnb = next((r for r in rows if "layernorm_bwd_lane" in r["Name"]), None)
+    bb = next((r for r in rows if "attn_fwd_kernel<false, true>" in r["Name"]), None)
+    ad = next((r for r in rows if "adamw_kernel" in r["Name"]), None)
+    tbl += f"""
+Sum of kernel time {tot / steps / 1e6:.1f} ms/step vs {d["ms_per_step"]:.1f} ms wall: the weight-gradient kernels run on a second HIP stream beside the
+dgrad chain, and the optimizer (`sumsq`, `adamw`, the W^T `transpose` launches) on a third beside the next step's
+frozen-backbone forward, so kernel durations overlap and stretch each other: `layernorm_bwd_lane` is 30-37 us alone,
+{float(lnb["AverageNs"]) / 1e3:.0f} us here; one `attn_fwd_kernel<false, true>` launch per step (the backbone's first attention) waits for
+`adamw_kernel` ({float(ad["AverageNs"]) / 1e6:.1f} ms) to leave the CUs (its maximum is {float(bb["MaxNs"]) / 1e3:.0f} us, its minimum {float(bb["MinNs"]) / 1e3:.0f} us) - which is why that overlap is
+worth only 0.2 ms at one GPU (its purpose is to hide the tail of the gradient all-reduce at N > 1).
+
+"""
+    path = os.path.join(P, "README.md")
+    s = open(path).read()
+    a, b = s.index("## Headline"), s.index("Template arguments of the GEMM kernels")
+    s = s[:a] + head + tbl + s[b:]
+    open(path, "w").write(s)
+    print(f"profiles/README.md: {d['value']:.0f} pairs/s, {d['ms_per_step']:.1f} ms/step, kernel sum {tot / steps / 1e6:.1f} ms")
+
+
+if __name__ == "__main__":
+    main()

@@ -116,8 +116,9 @@ class Engine:
         self._params_ready = ev
 
     def wait_params(self) -> None:
-        """Order the current stream after the pending optimizer step, if any (no host synchronisation)."""
-        ev, self._params_ready = self._params_ready, None
+        """Order the current stream after the last optimizer step, if it ran on the optimizer stream (no host
+        synchronisation). The event is kept until the next step replaces it: callers on different streams each wait."""
+        ev = self._params_ready
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 

@@ -1,0 +1,42 @@
+"""A/B: the step's main work on a high-priority HIP stream (weight-gradient and optimizer streams stay at the default, lower
+priority) against everything at the default priority. Interleaved rounds in one process."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stonkgs_amd.config import STonKGsConfig  # noqa: E402
+from stonkgs_amd.data import synthetic_batch  # noqa: E402
+from stonkgs_amd.stonkgs_model import STonKGsForPreTraining  # noqa: E402
+from stonkgs_amd.stonkgs_pretraining import Trainer, TrainingArguments  # noqa: E402
+
+cfg = STonKGsConfig()
+model = STonKGsForPreTraining(cfg, seed=0)
+tr = Trainer(model, TrainingArguments(per_device_train_batch_size=64, max_steps=10000))
+dev = model.device
+batches = [{k: v.to(dev) for k, v in synthetic_batch(64, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=1234 + i).items()}
+           for i in range(4)]
+print("priority range:", torch.cuda.Stream.priority_range(), flush=True)
+hi = torch.cuda.Stream(device=dev, priority=-1)
+for i in range(5):
+    tr.training_step(model, batches[i % 4])
+torch.cuda.synchronize()
+res = {True: [], False: []}
+for rnd in range(6):
+    for val in (True, False):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if val:
+            with torch.cuda.stream(hi):
+                for i in range(10):
+                    tr.training_step(model, batches[i % 4])
+        else:
+            for i in range(10):
+                tr.training_step(model, batches[i % 4])
+        torch.cuda.synchronize()
+        res[val].append((time.perf_counter() - t0) / 10 * 1e3)
+for val in (True, False):
+    r = sorted(res[val])
+    print(f"high-priority main stream={val}: median {r[len(r)//2]:.2f} ms  min {r[0]:.2f}  max {r[-1]:.2f}", flush=True)

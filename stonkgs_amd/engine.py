@@ -521,7 +521,10 @@ class Engine:
             dhs.zero_()
             # the persistent 256x256 kernel with 8 splits (<= 30 live tiles x 8 = one round of the CUs) against 128x128
             # tiles with 16: 734 us against 951 for the entity decoder (tools/bench_decoder_dgrad.py)
-            if self.decoder_dgrad_256 and npad >= 16384 and cap >= 1024 and H % 256 == 0:
+            # (not beside a running all-reduce - the entity decoder's bucket is in flight when the text decoder's dgrad is
+            # launched: a persistent launch would wait for the CUs RCCL holds, tools/hog_test.py)
+            if (self.decoder_dgrad_256 and npad >= 16384 and cap >= 1024 and H % 256 == 0
+                    and not (self.comm_overlap and nm != "ent")):
                 self.gemm(h["dl"], wt[wname], dhs, cap, H, npad, flags=hip.EPI_OUT_F32_ATOMIC | hip.EPI_DEBUG_V2,
                           split_k=8, m_dev=h["cnt"], alpha=gscale)
             else:

@@ -25,10 +25,11 @@ res = {True: [], False: []}
 for rnd in range(6):
     for val in (True, False):
         if attr.startswith("env:"):   # a library switch read per call with getenv: True = variable set
+            name, _, value = attr[4:].partition("=")   # env:NAME or env:NAME=VALUE
             if val:
-                os.environ[attr[4:]] = "1"
+                os.environ[name] = value or "1"
             else:
-                os.environ.pop(attr[4:], None)
+                os.environ.pop(name, None)
         elif attr.startswith("args:"):   # a TrainingArguments switch
             setattr(tr.args, attr[5:], val)
         else:

@@ -282,3 +282,28 @@ def test_gemm_tn_256_exact_and_matches_small_kernel(hip):
     hip.call("stonk_gemm_tn_bf16", hip.ptr(dY), Mo, hip.ptr(X), No, hip.ptr(dW2), No, 0, Mo, No, T, 1.0, 0,
              hip.ptr(k_dev), hip.stream_ptr())
     torch.testing.assert_close(dW2, dW, rtol=1e-5, atol=1e-4)
+
+
+def test_gemm_tn_256_operand_beyond_4gb(hip):
+    """The four-wave weight-gradient kernel re-bases its buffer resources per K tile: tokens that start more than 4 GB into
+    an operand (the entity decoder's dlogits are [16 384 x 175 104] bf16 = 5.7 GB) must contribute, with and without a
+    device-side token count. Exact data: one non-zero per token row of dY, small integers in X."""
+    T, Mo, No = 8448, 262144, 256          # T x Mo x 2 B = 4.43 GB; tokens >= 8192 lie beyond 2^32 bytes
+    free, _ = torch.cuda.mem_get_info()
+    if free < 12 * (1 << 30):
+        pytest.skip("needs 12 GB of free HBM")
+    dY = torch.zeros(T, Mo, device="cuda", dtype=torch.bfloat16)
+    cols = (torch.arange(T, device="cuda") * 977) % Mo
+    dY[torch.arange(T, device="cuda"), cols] = 1.0
+    X = ((torch.arange(T * No, device="cuda").reshape(T, No) % 13) - 6).to(torch.bfloat16)
+    for k in (T, 8300):                    # all tokens; a device-side count that ends beyond the 4 GB mark
+        k_dev = torch.tensor([k], device="cuda", dtype=torch.int32)
+        dW = torch.zeros(Mo, No, device="cuda")
+        hip.call("stonk_gemm_tn_bf16", hip.ptr(dY), Mo, hip.ptr(X), No, hip.ptr(dW), No, 0, Mo, No, T, 1.0, 0,
+                 hip.ptr(k_dev) if k < T else 0, hip.stream_ptr())
+        ref = torch.zeros(Mo, No, device="cuda")
+        ref.index_add_(0, cols[:k], X[:k].float())
+        assert torch.equal(dW, ref), k
+        assert float(dW[cols[8200]].abs().sum()) > 0      # a token beyond the 4 GB mark did land
+    del dY, X, dW, ref
+    torch.cuda.empty_cache()

@@ -10,17 +10,19 @@ from stonkgs_amd import _hip as hip  # noqa: E402
 from bench_kernels import timeit  # noqa: E402
 
 hip.lib()
-for M, N, K in [(32768, 3072, 768), (32768, 768, 3072), (32768, 768, 768)]:
+for M, N, K in [(32768, 3072, 768), (32768, 2304, 768), (16384, 3072, 768), (32768, 768, 3072), (32768, 768, 768)]:
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     B = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
     C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     aux = torch.randn(M, N, device="cuda").to(torch.bfloat16)
     res = torch.randn(M, N, device="cuda").to(torch.bfloat16)
     bias = torch.randn(N, device="cuda")
-    cases = {"plain": 0,  "bias": hip.EPI_BIAS, "bias+gelu+save": hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT,
-             "gelu_bwd": hip.EPI_GELU_BWD, "bias+resid": hip.EPI_BIAS | hip.EPI_RESID,
+    cases = {"plain": 0,  "bias": hip.EPI_BIAS, "bias+gelu": hip.EPI_BIAS | hip.EPI_GELU,
+             "bias+gelu+save": hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT,
+             "bias+gelu+save'": hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT | hip.EPI_AUX_GRAD,
+             "gelu_bwd": hip.EPI_GELU_BWD, "mul_aux": hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD, "bias+resid": hip.EPI_BIAS | hip.EPI_RESID,
              "bias+drop+resid": hip.EPI_BIAS | hip.EPI_RESID | hip.EPI_DROPOUT}
-    for kname, dbg in (("v1", hip.EPI_DEBUG_V1), ("v2", hip.EPI_DEBUG_V2)):
+    for kname, dbg in (("v1", hip.EPI_DEBUG_V1), ("v2", hip.EPI_DEBUG_V2), ("w4", hip.EPI_DEBUG_W4)):
         for cname, fl in cases.items():
             def f():
                 hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, M, N, K, fl | dbg,

@@ -43,7 +43,10 @@ def main():
   batch 2, {cb["cores"]} host threads of the GPU box): **{cb["value"]:.2f} pairs/s**. GPU/CPU = {d["value"] / cb["value"]:.0f} (a reported baseline, not a target).
 * The clock: under MFMA load the chip runs at 1.5-1.9 GHz, not 2.4 (SQ_BUSY_CYCLES / wall time in the PMC file above), so
   even a pure-MFMA loop tops out near 1.7 PFLOP/s here and the vendor library's best GEMM at 1.56; every fraction in this
-  repository is nevertheless quoted against the 2.5 PFLOP/s nominal peak.
+  repository is nevertheless quoted against the 2.5 PFLOP/s nominal peak. Over the whole step the socket draws about
+  1300 W at an average 2.2 GHz (`r01_final_power_clock_samples.log`: `rocm-smi --showpower --showclocks` every 3 s beside a
+  1500-step bench run; 295 W / 2.4 GHz before the first step) - the step runs at the power limit, which is one reason a kernel
+  that is faster in a benchmark loop of its own need not shorten the step.
 
 """
     tot = sum(float(r["TotalDurationNs"]) for r in rows)

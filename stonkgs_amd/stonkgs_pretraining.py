@@ -231,6 +231,11 @@ class Trainer:
         if resume_from_checkpoint:
             self.load_checkpoint(resume_from_checkpoint)
         it = iter(self._batches())
+        # hf:trainer.py resume semantics (ignore_data_skip=False): the batches the checkpointed run consumed are drawn
+        # and discarded, so the resumed run continues on the data - and, with the dropout counter restored by
+        # load_checkpoint, on the random masks - the uninterrupted run would have seen
+        for _ in range(self.global_step * self.args.gradient_accumulation_steps):
+            next(it)
         t0 = time.time()
         while self.global_step < self.args.max_steps:
             loss = self.training_step(self.model, next(it))
@@ -249,7 +254,8 @@ class Trainer:
         self.model.save_pretrained(d)
         torch.save(self.optimizer.state_dict(), os.path.join(d, "optimizer.pt"))
         with open(os.path.join(d, "trainer_state.json"), "w") as fh:
-            json.dump({"global_step": self.global_step, "log_history": self.log_history, "args": asdict(self.args)}, fh)
+            json.dump({"global_step": self.global_step, "log_history": self.log_history, "args": asdict(self.args),
+                       "dropout_counter": int(self.model.engine.seed_base)}, fh)
         ckpts = sorted((c for c in os.listdir(self.args.output_dir) if c.startswith("checkpoint-")),
                        key=lambda c: int(c.split("-")[1]))
         for old in ckpts[:-self.args.save_total_limit]:
@@ -264,7 +270,10 @@ class Trainer:
         self.model.load_state_dict(_load_weights_file(d), strict=False)
         self.optimizer.load_state_dict(torch.load(os.path.join(d, "optimizer.pt"), weights_only=True))
         with open(os.path.join(d, "trainer_state.json")) as fh:
-            self.global_step = json.load(fh)["global_step"]
+            state = json.load(fh)
+        self.global_step = state["global_step"]
+        if "dropout_counter" in state:   # (hf restores its RNG states from rng_state.pth; ours is one counter)
+            self.model.engine.seed_base = int(state["dropout_counter"])
 
     def save_model(self, output_dir: Optional[str] = None) -> None:
         self.model.save_pretrained(output_dir or self.args.output_dir)

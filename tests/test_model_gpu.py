@@ -3,6 +3,8 @@
   (2) the CPU oracle on fresh seeded inputs,
 through the reference's own module contract (constructor, load_state_dict, forward, loss.backward, Trainer).
 bf16 compute vs fp32 reference: tolerances are stated per check."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -186,3 +188,50 @@ def test_dropout_training_mode_is_statistically_consistent(hip):
     with torch.no_grad():
         le = float(model(**batch)[0])
     assert abs(le - float(gold["loss"])) < 2e-2  # eval mode switches every dropout off
+
+
+def test_checkpoint_resume_continues_the_uninterrupted_run(hip, tmp_path):
+    """Trainer.train with save_steps, then a fresh model resumed from the middle checkpoint (ref:stonkgs_pretraining.py:
+    196-223: get_last_checkpoint -> train(resume_from_checkpoint)): parameters, Adam moments, step count, the position in
+    the data stream and the dropout counter are restored, so the resumed run ends where the uninterrupted one did (up to
+    the reordering of fp32 atomic sums). Dropout is ON: a resumed run that drew different masks would not agree."""
+    from stonkgs_amd.data import synthetic_batch
+    from stonkgs_amd.stonkgs_pretraining import Trainer, TrainingArguments, get_last_checkpoint
+
+    cfg, sd, tsv_rows, batch, gold, meta = load_case("g2_hipsmall")
+    S = cfg.max_position_embeddings
+    ds = []
+    for i in range(4):   # a dataset of already collated batches (the Trainer accepts any iterable of them)
+        ds.append({k: v.cuda() for k, v in synthetic_batch(3, cfg.vocab_size, len(tsv_rows), S, seed=50 + i, min_text=8).items()})
+
+    def run(out_dir, max_steps, resume=None):
+        model = _build(cfg, sd, tsv_rows, dropout=0.1)
+        tr = Trainer(model, TrainingArguments(output_dir=str(out_dir), max_steps=max_steps, learning_rate=1e-3, save_steps=2,
+                                              per_device_train_batch_size=3, logging_steps=1, save_total_limit=2), ds)
+        res = tr.train(resume_from_checkpoint=resume)
+        return model, tr, res
+
+    full, tr_full, res_full = run(tmp_path / "full", 6)
+    assert sorted(os.listdir(tmp_path / "full")) == ["checkpoint-4", "checkpoint-6"]   # save_total_limit = 2
+    assert get_last_checkpoint(str(tmp_path / "full")).endswith("checkpoint-6")
+    # the interrupted run: same arguments (the learning-rate schedule spans all 6 steps), stopped after step 2
+    part = _build(cfg, sd, tsv_rows, dropout=0.1)
+    tr_part = Trainer(part, TrainingArguments(output_dir=str(tmp_path / "part"), max_steps=6, learning_rate=1e-3,
+                                              save_steps=2, per_device_train_batch_size=3, save_total_limit=2), ds)
+    for i in range(2):
+        tr_part.training_step(part, ds[i])
+    tr_part.save_checkpoint()
+    ck = get_last_checkpoint(str(tmp_path / "part"))
+    assert ck.endswith("checkpoint-2")
+    resumed, tr_res, res = run(tmp_path / "part", 6, resume=ck)
+    assert res["global_step"] == 6 and tr_res.optimizer.step_count == 6
+    assert resumed.engine.seed_base == full.engine.seed_base
+    assert res["training_loss"] == pytest.approx(res_full["training_loss"], rel=2e-3)
+    a = {k: v.detach().float() for k, v in full.named_parameters()}
+    b = {k: v.detach().float() for k, v in resumed.named_parameters()}
+    diff = torch.cat([(a[k] - b[k]).abs().flatten() for k in a])
+    assert float((diff > 1e-4).float().mean()) < 2e-3, float((diff > 1e-4).float().mean())
+    # and the checkpoint is a plain HF-layout directory
+    last = get_last_checkpoint(str(tmp_path / "part"))   # (checkpoint-2 itself was rotated out: save_total_limit = 2)
+    assert last.endswith("checkpoint-6")
+    assert {"config.json", "pytorch_model.bin", "optimizer.pt", "trainer_state.json"} <= set(os.listdir(last))

@@ -167,3 +167,18 @@ def test_cv_splits_match_reference_vectors_and_weighted_f1_matches_sklearn():
     assert weighted_f1_score([0, 0, 1], [0, 0, 0]) == pytest.approx(f1_score([0, 0, 1], [0, 0, 0], average="weighted"))
     ds = INDRADataset({"input_ids": [[1, 2], [3, 4]], "attention_mask": [[1, 1], [1, 0]], "other": [0, 0]}, [1, 0])
     assert len(ds) == 2 and set(ds[1]) == {"input_ids", "attention_mask", "labels"} and int(ds[0]["labels"]) == 1
+
+
+def test_pretrain_refuses_a_non_empty_output_dir_without_checkpoint(tmp_path):
+    """ref:stonkgs_pretraining.py:203-207: an existing, non-empty training_dir with no checkpoint in it raises unless
+    overwrite_output_dir; get_last_checkpoint picks the highest step (host logic: no model is touched before the check)."""
+    from stonkgs_amd.stonkgs_pretraining import get_last_checkpoint, pretrain_stonkgs
+
+    (tmp_path / "stale.txt").write_text("x")
+    with pytest.raises(ValueError):
+        pretrain_stonkgs(object(), [], training_dir=str(tmp_path))
+    assert get_last_checkpoint(str(tmp_path)) is None and get_last_checkpoint(str(tmp_path / "missing")) is None
+    for n in (2, 10, 4):
+        (tmp_path / f"checkpoint-{n}").mkdir()
+    (tmp_path / "checkpoint-final").mkdir()   # not a step directory
+    assert get_last_checkpoint(str(tmp_path)).endswith("checkpoint-10")

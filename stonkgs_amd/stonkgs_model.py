@@ -317,9 +317,17 @@ class STonKGsForPreTraining(nn.Module):
             raise FileNotFoundError("set STONKGS_PRETRAINED_DIR to a local copy of stonkgs/stonkgs-150k")
         return cls.from_pretrained(path, **kwargs)
 
-    def save_pretrained(self, path: str) -> None:
+    def save_pretrained(self, path: str, safe_serialization: bool = False) -> None:
+        """HF layout: config.json + pytorch_model.bin, or model.safetensors with ``safe_serialization=True`` (what newer
+        HF versions write by default; `from_pretrained` reads either)."""
         self.config.save_pretrained(path)
-        torch.save({k: v.detach().cpu() for k, v in self.state_dict().items()}, os.path.join(path, "pytorch_model.bin"))
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        if safe_serialization:
+            from safetensors.torch import save_file
+
+            save_file(sd, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+        else:
+            torch.save(sd, os.path.join(path, "pytorch_model.bin"))
 
     # -------------------------------------------------------------- forward
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, masked_lm_labels=None,

@@ -235,3 +235,24 @@ def test_checkpoint_resume_continues_the_uninterrupted_run(hip, tmp_path):
     last = get_last_checkpoint(str(tmp_path / "part"))   # (checkpoint-2 itself was rotated out: save_total_limit = 2)
     assert last.endswith("checkpoint-6")
     assert {"config.json", "pytorch_model.bin", "optimizer.pt", "trainer_state.json"} <= set(os.listdir(last))
+
+
+@pytest.mark.parametrize("safe", [False, True])
+def test_save_pretrained_round_trip(g2, tmp_path, safe):
+    """f3: save_pretrained -> from_pretrained(local_dir) in both HF weight formats: every state-dict entry (dead parameters
+    included) comes back bit for bit, and the reloaded model computes the same loss."""
+    from stonkgs_amd.stonkgs_model import STonKGsForPreTraining
+
+    cfg, sd, tsv_rows, batch, gold, meta, model = g2
+    model.save_pretrained(str(tmp_path), safe_serialization=safe)
+    assert os.path.exists(tmp_path / ("model.safetensors" if safe else "pytorch_model.bin"))
+    again = STonKGsForPreTraining.from_pretrained(str(tmp_path), kg_embeddings=tsv_rows)
+    a, b = model.state_dict(), again.state_dict()
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    model.eval()
+    again.eval()
+    with torch.no_grad():
+        la, lb = model(**batch, return_dict=True).loss, again(**batch, return_dict=True).loss
+    assert float(la) == pytest.approx(float(lb), rel=1e-6)   # (the per-row loss terms are summed by float atomics)

@@ -189,7 +189,7 @@ def main():
     if rank == 0:
         pairs = args.batch * world * args.steps
         value = pairs / dt
-        out = {"metric": "text-triple pairs/sec (whole node), seq_len=512 hidden=768", "value": round(value, 2),
+        out = {"metric": "text-triple pairs/sec (whole node), seq_len=512 hidden=768, 1/2/4/8 MI355X", "value": round(value, 2),
                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

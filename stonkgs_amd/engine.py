@@ -233,7 +233,8 @@ class Engine:
         w = S.bf16_view
         f = S.view
         qkv = self.buf(f"{tag}.qkv", (T, 3 * H))
-        self.gemm(x, w(prefix + ".attention.self.qkv.weight"), qkv, T, 3 * H, H, flags=hip.EPI_BIAS,
+        w4 = hip.EPI_DEBUG_W4 if os.environ.get("STONK_FWD_W4") else 0   # (development switch, tools/fwd_w4_probe.py)
+        self.gemm(x, w(prefix + ".attention.self.qkv.weight"), qkv, T, 3 * H, H, flags=hip.EPI_BIAS | w4,
                   bias=f(prefix + ".attention.self.qkv.bias"))
         ctx = self.buf(f"{tag}.ctx", (T, H))
         lse = self.buf(f"{tag}.lse", (B, NH, seq), F32)
@@ -251,7 +252,7 @@ class Engine:
                  st1[1].data_ptr(), T, H, cfg.layer_norm_eps, 0, 0.0, 0, st)
         g = self.buf(f"{tag}.g", (T, I))
         u = self.buf(f"{tag}.u", (T, I)) if save is not None else None
-        fl = hip.EPI_BIAS | hip.EPI_GELU | ((hip.EPI_SAVE_PREACT | hip.EPI_AUX_GRAD) if save is not None else 0)
+        fl = hip.EPI_BIAS | hip.EPI_GELU | ((hip.EPI_SAVE_PREACT | hip.EPI_AUX_GRAD) if save is not None else w4)
         self.gemm(h1, w(prefix + ".intermediate.dense.weight"), g, T, I, H, flags=fl,
                   bias=f(prefix + ".intermediate.dense.bias"), aux=u)
         s2 = self.buf(f"{tag}.s2", (T, H))

@@ -18,6 +18,11 @@ dev = model.device
 batches = [{k: v.to(dev) for k, v in synthetic_batch(64, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=1234 + i).items()}
            for i in range(4)]
 attr = sys.argv[1] if len(sys.argv) > 1 else "overlap_wgrad"
+for fixed in sys.argv[2:]:   # further arguments pin switches for the whole run: engine.NAME=0/1 or args.NAME=0/1
+    where, _, rest = fixed.partition(".")
+    name, _, value = rest.partition("=")
+    setattr(model.engine if where == "engine" else tr.args, name, bool(int(value)))
+    print(f"pinned {where}.{name} = {bool(int(value))}", flush=True)
 for i in range(5):
     tr.training_step(model, batches[i % 4])
 torch.cuda.synchronize()

@@ -20,6 +20,10 @@ def main():
     tn = next(r for r in pmc if r["kernel"].startswith("gemm_tn_w4"))
     total_gb = float(next(r for r in pmc if r["kernel"] == "TOTAL")["GB_per_step"])
     rf, ag, cb = d["roofline"], d["all_gemm"], d["cpu_baseline"]
+    sq = list(csv.DictReader(open(os.path.join(P, "r01_final_pmc_mfma.csv"))))
+    mf_total = 100 * float(next(r for r in sq if r["kernel"] == "TOTAL")["mfma_pipe_utilisation"])
+    mf_tn = 100 * float(next(r for r in sq if r["kernel"].startswith("gemm_tn_w4"))["mfma_pipe_utilisation"])
+    mf_tn160 = mf_tn * 256 / 160
     head = f"""## Headline (r01_final_bench.json)
 
 * **{d["value"]:.0f} text-triple pairs/s on one MI355X, {d["ms_per_step"]:.1f} ms per training step** at BASELINE config 2 (12L/768h, V = 28 996,
@@ -39,6 +43,11 @@ def main():
   forward read 455 MB per launch for 151 MB of Q/K/V (the four 128-row blocks of a head sat on four XCDs), the entity
   decoder 3.8 GB for a 269 MB weight, and stand-alone (252 or 243 workgroups, not a multiple of 8) the weight-gradient
   kernel 866 MB for 201 MB - all three were work->XCD mapping mistakes, now fixed.
+* matrix-pipe utilisation from the SQ counters (`r01_final_pmc_mfma.csv`, `tools/summarize_pmc_sq.py`: MFMA-busy cycles per
+  SIMD over shader-busy cycles, each kernel profiled alone): {mf_total:.0f} % over the whole step; `gemm_tn_w4_kernel` {mf_tn:.0f} % on the 160 CUs
+  it is held to ({mf_tn160:.0f} % of those), the 128x128 kernels 34-41 %, the eight-wave 256x256 kernel 29-33 % with the step's
+  epilogues (46 % on the long-K decoder dgrad), attention 21-25 %. Their waves spend 40-49 % of their time parked at a
+  wait or a barrier (`wait_any_over_wave_cycles`): the K loops are latency- and barrier-paced, not MFMA-paced.
 * CPU baseline (`cpu_baseline`, the oracle = CPU restatement of the reference's HuggingFace path, fp32, same model shape,
   batch 2, {cb["cores"]} host threads of the GPU box): **{cb["value"]:.2f} pairs/s**. GPU/CPU = {d["value"] / cb["value"]:.0f} (a reported baseline, not a target).
 * The clock: under MFMA load the chip runs at 1.5-1.9 GHz, not 2.4 (SQ_BUSY_CYCLES / wall time in the PMC file above), so

@@ -335,10 +335,33 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, M * ldr_b, 0x00020000);
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.aux, 0, M * ldx_b, 0x00020000);
     const int wm0 = w.m0 + (wv >> 1) * 128, wn0 = w.n0 + (wv & 1) * 128;
+    // Side operand (residual OR saved GELU input / GELU', never both here): the four 16-byte pieces a lane needs in round
+    // k + 1 are requested as soon as round k has consumed its own - requested at their point of use, every round paid a full
+    // memory latency (a 50 MB residual cost 35 us where its HBM time is 10). 16 registers, reused round after round
+    // (a second set, one full round ahead, measured the same and spilled 70 more registers).
+    constexpr bool SIDE_X = (EPI >= 0) && (EPI & STONK_EPI_GELU_BWD) != 0;
+    constexpr bool SIDE_R = (EPI >= 0) && (EPI & STONK_EPI_RESID) != 0 && !SIDE_X;
+    constexpr bool SIDE = SIDE_X || SIDE_R;
+    bf16x8 sd[1][4];
+    auto side_request = [&](const int round, bf16x8 (&dst)[4]) {
+      if (!SIDE) return;
+      const int bi2 = round >> 1, qb2 = round & 1;
+      const int mrow0 = wm0 + bi2 * 32, n0 = wn0 + qb2 * 64;
+      const int oob = (n0 + c8 * 8 < N) ? 0 : 0x40000000;
+      const int vo = rrow * (SIDE_X ? ldx_b : ldr_b) + c8 * 16 + oob;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int mrow = mrow0 + it * 8;
+        dst[it] = __builtin_bit_cast(bf16x8, SIDE_X ? __builtin_amdgcn_raw_buffer_load_b128(rX, vo + mrow * ldx_b + n0 * 2, 0, 0)
+                                                   : __builtin_amdgcn_raw_buffer_load_b128(rR, vo + mrow * ldr_b + n0 * 2, 0, 0));
+      }
+    };
+    side_request(0, sd[0]);
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
+        const int round = bi * 2 + qb;
         const int mrow0 = wm0 + bi * 32;
         const int n0 = wn0 + qb * 64;
         const int n = n0 + c8 * 8;
@@ -375,10 +398,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
             const f32x4 q1 = *(const f32x4*)(ep + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
             float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
             SideOps so;
-            if (flags & STONK_EPI_GELU_BWD)
-              so.aux = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rX, voX + mrow * ldx_b + n0 * 2, 0, 0));
-            if (flags & STONK_EPI_RESID)
-              so.res = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rR, voR + mrow * ldr_b + n0 * 2, 0, 0));
+            if (SIDE) {
+              so.aux = so.res = sd[0][it];
+            } else {   // run-time flags (EPI < 0) or both operands at once: requested here
+              if (flags & STONK_EPI_GELU_BWD)
+                so.aux = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rX, voX + mrow * ldx_b + n0 * 2, 0, 0));
+              if (flags & STONK_EPI_RESID)
+                so.res = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rR, voR + mrow * ldr_b + n0 * 2, 0, 0));
+            }
             // (bias, GELU, GELU', dropout, residual on the 8 values; the saved pre-activation leaves from here as well)
             if (flags & STONK_EPI_BIAS) {
 #pragma unroll
@@ -407,6 +434,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
               __builtin_amdgcn_raw_buffer_store_b128(hi, rC, voC + mrow * ldc_b + n0 * 4 + 16, 0, 0);
             }
           }
+          if (round + 1 < 8) side_request(round + 1, sd[0]);   // flies while the next round is written to the slab
         }
         __builtin_amdgcn_wave_barrier();
       }

@@ -79,6 +79,12 @@ class Engine:
         # stream (dgrad through GELU) then takes the 128x128 kernel, whose grid the hardware schedules dynamically.
         self.comm_overlap = False
         self.decoder_dgrad_256 = True
+        # Launches with a second [M,N] operand on the four-wave NT kernel (its epilogue requests the side operand one round
+        # ahead): interleaved A/B in the step, each switch alone -0.54 / -0.17 / -0.72 ms, all three 37.1 -> 35.9 ms. The
+        # backward ones are persistent launches: not beside a running all-reduce (comm_overlap, tools/hog_test.py).
+        self.w4_fwd_down = True      # FFN-down forward: bias + dropout + residual (157 against 174 us alone)
+        self.w4_gb = True            # dgrad through GELU, multiplying by the saved GELU' (172 against 200 us)
+        self.w4_dgrad_resid = True   # dgrad into the residual stream: FFN-up, QKV (152 against 177 us)
         self.f16_logits = True      # label-sparse decoder logits in fp16 (False: fp32, 4 more bytes of HBM traffic per logit)
         self._wstream: Optional[torch.cuda.Stream] = None
         # The optimizer (grad-norm, AdamW, W^T refresh: ~2 ms of HBM-bound work) runs on a third stream; the next step's
@@ -257,7 +263,8 @@ class Engine:
                   bias=f(prefix + ".intermediate.dense.bias"), aux=u)
         s2 = self.buf(f"{tag}.s2", (T, H))
         fl = hip.EPI_BIAS | hip.EPI_RESID | (hip.EPI_DROPOUT if p_hid > 0 else 0)
-        self.gemm(g, w(prefix + ".output.dense.weight"), s2, T, H, I, flags=fl, bias=f(prefix + ".output.dense.bias"),
+        self.gemm(g, w(prefix + ".output.dense.weight"), s2, T, H, I, flags=fl | (hip.EPI_DEBUG_W4 if self.w4_fwd_down else 0),
+                  bias=f(prefix + ".output.dense.bias"),
                   resid=h1, drop_p=p_hid, seed=self.seed(lidx, 3))
         y = self.buf(f"{prefix}.y" if save is not None else f"tmp.y{lidx & 1}", (T, H))
         st2 = self.buf(f"{tag}.st2", (2, T), F32)
@@ -297,13 +304,16 @@ class Engine:
         self.wgrad(df, sv["g"], g_(prefix + ".output.dense.weight"), g_(prefix + ".output.dense.bias"), H, I, T)
         du = self.buf(f"b.du.{par}", (T, I))
         self.gemm(df, wt[prefix + ".output.dense.weight"], du, T, I, H,
-                  flags=hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD | (hip.EPI_DEBUG_V1 if self.comm_overlap else 0),
+                  flags=hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD | (hip.EPI_DEBUG_V1 if self.comm_overlap else
+                                                                (hip.EPI_DEBUG_W4 if self.w4_gb else 0)),
                   aux=sv["u"])
         # ---- FFN up
         self.wgrad(du, sv["h1"], g_(prefix + ".intermediate.dense.weight"), g_(prefix + ".intermediate.dense.bias"), I, H,
                    T)
         dh1 = self.buf("b.dh1", (T, H))
-        self.gemm(du, wt[prefix + ".intermediate.dense.weight"], dh1, T, H, I, flags=hip.EPI_RESID, resid=ds2)
+        self.gemm(du, wt[prefix + ".intermediate.dense.weight"], dh1, T, H, I,
+                  flags=hip.EPI_RESID | (hip.EPI_DEBUG_W4 if self.w4_dgrad_resid and not self.comm_overlap else 0),
+                  resid=ds2)
         # ---- LN1 backward
         ds1 = self.buf(f"b.ds1.{par}", (T, H))
         da = self.buf(f"b.da.{par}", (T, H)) if p_hid > 0 else None
@@ -331,7 +341,9 @@ class Engine:
         self.wgrad(dqkv, sv["x"], g_(prefix + ".attention.self.qkv.weight"), g_(prefix + ".attention.self.qkv.bias"),
                    3 * H, H, T)
         dx = self.buf(f"b.dx{lidx & 1}", (T, H))
-        self.gemm(dqkv, wt[prefix + ".attention.self.qkv.weight"], dx, T, H, 3 * H, flags=hip.EPI_RESID, resid=ds1)
+        self.gemm(dqkv, wt[prefix + ".attention.self.qkv.weight"], dx, T, H, 3 * H,
+                  flags=hip.EPI_RESID | (hip.EPI_DEBUG_W4 if self.w4_dgrad_resid and not self.comm_overlap else 0),
+                  resid=ds1)
         if self._wstream is not None and self.overlap_wgrad and self.gemm_timer is None:
             done = torch.cuda.Event()
             done.record(self._wstream)

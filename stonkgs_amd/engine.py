@@ -82,6 +82,8 @@ class Engine:
         # Launches with a second [M,N] operand on the four-wave NT kernel (its epilogue requests the side operand one round
         # ahead): interleaved A/B in the step, each switch alone -0.54 / -0.17 / -0.72 ms, all three 37.1 -> 35.9 ms. The
         # backward ones are persistent launches: not beside a running all-reduce (comm_overlap, tools/hog_test.py).
+        self.w4_fwd_out = True       # attention-output projection forward (same time alone, -0.2 ms in the step)
+        self.w4_dgrad_out = False    # (A/B) attention-output projection dgrad
         self.w4_fwd_down = True      # FFN-down forward: bias + dropout + residual (157 against 174 us alone)
         self.w4_gb = True            # dgrad through GELU, multiplying by the saved GELU' (172 against 200 us)
         self.w4_dgrad_resid = True   # dgrad into the residual stream: FFN-up, QKV (152 against 177 us)
@@ -169,7 +171,8 @@ class Engine:
         # stream) the kernel is held to 160 CUs' worth of workgroups (split_k = -160): another -1.5 ms
         # ... and so does the entity decoder's 175 104 x 768 gradient (2052 unsplit tiles, device-side token count, 5.7 GB
         # operand extent - the kernel re-bases its buffer resources per K tile): 863 us against 966 alone, -0.27 ms in the step
-        if tiles >= 100 and K >= 16384 and M % 256 == 0 and N % 256 == 0 and not os.environ.get("STONK_TN_V1"):
+        min_tiles = 36 if os.environ.get("STONK_TN_SMALL") else 100   # (A/B: the 768 x 768 gradients as well)
+        if tiles >= min_tiles and K >= 16384 and M % 256 == 0 and N % 256 == 0 and not os.environ.get("STONK_TN_V1"):
             return -int(os.environ.get("STONK_TN_CUS", "160")) if side_stream else 0
         return max(1, min(32, 480 // tiles, K // 64))
 
@@ -249,7 +252,8 @@ class Engine:
                  self.seed(lidx, 1), st)
         s1 = self.buf(f"{tag}.s1", (T, H))
         fl = hip.EPI_BIAS | hip.EPI_RESID | (hip.EPI_DROPOUT if p_hid > 0 else 0)
-        self.gemm(ctx, w(prefix + ".attention.output.dense.weight"), s1, T, H, H, flags=fl,
+        self.gemm(ctx, w(prefix + ".attention.output.dense.weight"), s1, T, H, H,
+                  flags=fl | (hip.EPI_DEBUG_W4 if self.w4_fwd_out else 0),
                   bias=f(prefix + ".attention.output.dense.bias"), resid=x, drop_p=p_hid, seed=self.seed(lidx, 2))
         h1 = self.buf(f"{tag}.h1", (T, H))
         st1 = self.buf(f"{tag}.st1", (2, T), F32)
@@ -328,7 +332,8 @@ class Engine:
         self.wgrad(da, sv["ctx"], g_(prefix + ".attention.output.dense.weight"),
                    g_(prefix + ".attention.output.dense.bias"), H, H, T)
         dctx = self.buf("b.dctx", (T, H))
-        self.gemm(da, wt[prefix + ".attention.output.dense.weight"], dctx, T, H, H)
+        self.gemm(da, wt[prefix + ".attention.output.dense.weight"], dctx, T, H, H,
+                  flags=hip.EPI_DEBUG_W4 if self.w4_dgrad_out and not self.comm_overlap else 0)
         # ---- attention core
         qkv = sv["qkv"]
         dqkv = self.buf(f"b.dqkv.{par}", (T, 3 * H))

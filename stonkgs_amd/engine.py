@@ -84,6 +84,7 @@ class Engine:
         # backward ones are persistent launches: not beside a running all-reduce (comm_overlap, tools/hog_test.py).
         self.w4_fwd_out = True       # attention-output projection forward (same time alone, -0.2 ms in the step)
         self.w4_dgrad_out = False    # (A/B) attention-output projection dgrad
+        self.w4_fwd_up = False       # (A/B) encoder FFN-up forward: bias + GELU + saved GELU'
         self.w4_fwd_down = True      # FFN-down forward: bias + dropout + residual (157 against 174 us alone)
         self.w4_gb = True            # dgrad through GELU, multiplying by the saved GELU' (172 against 200 us)
         self.w4_dgrad_resid = True   # dgrad into the residual stream: FFN-up, QKV (152 against 177 us)
@@ -263,6 +264,8 @@ class Engine:
         g = self.buf(f"{tag}.g", (T, I))
         u = self.buf(f"{tag}.u", (T, I)) if save is not None else None
         fl = hip.EPI_BIAS | hip.EPI_GELU | ((hip.EPI_SAVE_PREACT | hip.EPI_AUX_GRAD) if save is not None else w4)
+        if save is not None and self.w4_fwd_up:
+            fl |= hip.EPI_DEBUG_W4
         self.gemm(h1, w(prefix + ".intermediate.dense.weight"), g, T, I, H, flags=fl,
                   bias=f(prefix + ".intermediate.dense.bias"), aux=u)
         s2 = self.buf(f"{tag}.s2", (T, H))

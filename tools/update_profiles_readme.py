@@ -45,9 +45,10 @@ def main():
   kernel 866 MB for 201 MB - all three were work->XCD mapping mistakes, now fixed.
 * matrix-pipe utilisation from the SQ counters (`r01_final_pmc_mfma.csv`, `tools/summarize_pmc_sq.py`: MFMA-busy cycles per
   SIMD over shader-busy cycles, each kernel profiled alone): {mf_total:.0f} % over the whole step; `gemm_tn_w4_kernel` {mf_tn:.0f} % on the 160 CUs
-  it is held to ({mf_tn160:.0f} % of those), the 128x128 kernels 34-41 %, the eight-wave 256x256 kernel 29-33 % with the step's
-  epilogues (46 % on the long-K decoder dgrad), attention 21-25 %. Their waves spend 40-49 % of their time parked at a
-  wait or a barrier (`wait_any_over_wave_cycles`): the K loops are latency- and barrier-paced, not MFMA-paced.
+  it is held to ({mf_tn160:.0f} % of those), the four-wave NT kernel 39-51 % with its side-operand epilogues (the 128x128 kernel
+  it replaced there: 34-41 %), the eight-wave 256x256 kernel 29-33 % with the step's epilogues (46 % on the long-K decoder
+  dgrad), attention 21-25 %. The eight-wave kernel's waves spend 43-47 % of their time parked at a wait or a barrier
+  (`wait_any_over_wave_cycles`; the four-wave kernels 18-36 %): its K loops are latency- and barrier-paced, not MFMA-paced.
 * CPU baseline (`cpu_baseline`, the oracle = CPU restatement of the reference's HuggingFace path, fp32, same model shape,
   batch 2, {cb["cores"]} host threads of the GPU box): **{cb["value"]:.2f} pairs/s**. GPU/CPU = {d["value"] / cb["value"]:.0f} (a reported baseline, not a target).
 * The clock: under MFMA load the chip runs at 1.5-1.9 GHz, not 2.4 (SQ_BUSY_CYCLES / wall time in the PMC file above), so

@@ -182,3 +182,31 @@ def test_pretrain_refuses_a_non_empty_output_dir_without_checkpoint(tmp_path):
         (tmp_path / f"checkpoint-{n}").mkdir()
     (tmp_path / "checkpoint-final").mkdir()   # not a step directory
     assert get_last_checkpoint(str(tmp_path)).endswith("checkpoint-10")
+
+
+def test_bench_contract_constants():
+    """bench.py reports BASELINE.json's metric under that exact name, defaults to one GPU and a short run, and the README
+    generator finds every artefact it quotes (no GPU: only the module's constants and argument defaults are touched)."""
+    import importlib
+    import json
+    import sys
+
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    assert f'"metric": "{metric}"' in open(os.path.join(ROOT, "bench.py")).read()
+    old = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        a = bench.parse()
+    finally:
+        sys.argv = old
+    assert a.gpus == 1 and 0 < a.steps <= 50 and 0 < a.warmup <= 10 and a.batch == 64
+    assert bench.PEAK_BF16_TFLOPS == 2500.0
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_final_bench.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["metric"] == metric and line["config"]["workload"] and line["vs_baseline"] is None
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])

@@ -24,12 +24,50 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# gemm_tn_w4_kernel, average of its 37 launches per step: 337.7 MB fetched (FETCH_SIZE doubled, the gfx950 correction of
-# MI355X_MICROARCH.md) + 61.1 MB of float atomics written (profiles/r01_final_pmc_traffic.csv)
-TN_W4_TRAFFIC_BYTES = 398.8e6
+# HBM-side bytes per launch of the dominant kernel, from separate rocprofv3 --pmc passes over this command:
+# gemm_tn_w4_kernel (12L/768, average of its 37 launches per step): 337.7 MB fetched (FETCH_SIZE doubled, the gfx950
+# correction of MI355X_MICROARCH.md) + 61.1 MB of float atomics written (profiles/r01_final_pmc_traffic.csv)
+TRAFFIC_BYTES = {("150k", "tn_w4"): 398.8e6}
+KERNEL_NOTES = {
+    "tn_w4": "gemm_tn_w4_kernel (weight + bias gradients: bf16 MFMA 32x32x16, 256x256 tiles over 64-token steps, four waves, "
+             "transposed LDS reads, split-K fp32 atomics)",
+    "tn": "gemm_tn_kernel (weight + bias gradients on 128x128 tiles)",
+    "nt": "NT forward / dgrad GEMMs (gemm_w4_kernel, gemm256_kernel, gemm_nt_kernel)",
+}
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
 # algorithmic GFLOP per text-triple pair, 12L/768/S=512, label-sparse decoders
 GFLOP_PER_PAIR_STEP = 373.4
+# BASELINE.json configs[1]/[2] (the headline) and configs[3] (24L/1024h: no reference counterpart - the reference can only
+# build BioBERT's 12L/768; frozen backbone and node2vec table are instantiated at width 1024)
+MODELS = {
+    "150k": dict(batch=64, cfg={}, name="STonKGs-150k pretraining step (12L/768h, V=28996, K=175094)"),
+    "24L1024": dict(batch=32, cfg=dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                                       intermediate_size=4096),
+                    name="STonKGs 24L/1024h synthetic scale-up pretraining step (V=28996, K=175094, frozen backbone and "
+                         "table at width 1024)"),
+}
+
+
+def encoder_gflop_per_pair(cfg) -> float:
+    """Forward + backward GFLOP per pair of the attention+FFN path of the trainable encoder (the path the 40 %-of-MFMA-peak
+    target of BASELINE.json refers to; 12L/768: 289.9)."""
+    H, I, L, S = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.max_position_embeddings
+    return 3 * L * (2 * S * (4 * H * H + 2 * H * I) + 4 * S * S * H) / 1e9
+
+
+def gflop_per_pair(cfg) -> float:
+    """Algorithmic GFLOP of one training step per text-triple pair (SURVEY section 8d's accounting: 1 MAC = 2 FLOP,
+    backward = 2 x forward for trainable blocks, frozen backbone forward only at S/2, label-sparse decoders on
+    int(half * 0.15) labelled rows per half). 12L/768: 373.4."""
+    H, I, L, S = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.max_position_embeddings
+    half = S // 2
+
+    def enc(seq):   # forward FLOPs of one layer on `seq` tokens
+        return 2 * seq * (4 * H * H + 2 * H * I) + 4 * seq * seq * H
+
+    lab = int(half * 0.15)
+    f = 3 * L * enc(S) + L * enc(half) + 3 * 2 * S * H * H + 3 * 2 * lab * H * (cfg.vocab_size + cfg.kg_vocab_size)
+    return f / 1e9
 
 
 def parse():
@@ -37,10 +75,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE config 2: 64)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (BASELINE config 2: 64; 24L1024: 32)")
+    ap.add_argument("--model", choices=sorted(MODELS), default="150k",
+                    help="150k = BASELINE config 2/3 (12L/768h, the headline); 24L1024 = config 4 (synthetic scale-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = MODELS[args.model]["batch"]
+    return args
 
 
 def log(msg):
@@ -59,9 +102,10 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(cfg, seconds_budget=25.0):
+def cpu_baseline(cfg, seconds_budget=28.0):
     """The oracle (CPU restatement of the reference's HuggingFace path, pinned by tests/test_oracle_golden.py) timed
-    on this host's cores: full training steps at the SAME model shape on a bounded sample (B = 2)."""
+    on this host's cores: full training steps at the SAME model shape on a bounded sample - batch 8 as SURVEY section 8d
+    specifies, at all the threads this process may use and, as a second point, at 8 threads."""
     from oracle import stonkgs_oracle as orc
     from stonkgs_amd.data import synthetic_batch
 
@@ -69,32 +113,69 @@ def cpu_baseline(cfg, seconds_budget=25.0):
                             num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
                             intermediate_size=cfg.intermediate_size, max_position_embeddings=cfg.max_position_embeddings)
     cores = host_cores()
-    torch.set_num_threads(cores)
-    log(f"cpu_baseline: {cores} threads, building fp32 weights")
+    log(f"cpu_baseline: {cores} threads available, building fp32 weights")
     sd = orc.init_state_dict(ocfg, seed=0, bf16_exact=False)
     table = torch.randn(ocfg.kg_vocab_size + 3, ocfg.hidden_size) * 0.3
-    B = 2
+    B = 8
     batch = synthetic_batch(B, ocfg.vocab_size, ocfg.kg_vocab_size, ocfg.max_position_embeddings, seed=4321)
     state = orc.AdamState()
-    tw = time.time()
-    orc.train_step(sd, ocfg, table, batch, state)  # warm-up (allocations, oneDNN primitive caches)
-    log(f"cpu_baseline: warm-up step {time.time() - tw:.1f} s")
-    n, t0 = 0, time.time()
-    while n < 1 or (time.time() - t0 < seconds_budget and n < 8):
-        orc.train_step(sd, ocfg, table, batch, state)
-        n += 1
-        log(f"cpu_baseline: step {n} at {time.time() - t0:.1f} s")
-    dt = time.time() - t0
-    return {"value": B * n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} full fp32 training steps of the CPU oracle at the same model shape, batch {B} "
-                      f"(seq 512, V={ocfg.vocab_size}, K={ocfg.kg_vocab_size}), torch {torch.__version__}"}
+
+    def timed(threads, budget, max_steps):
+        torch.set_num_threads(threads)
+        tw = time.time()
+        orc.train_step(sd, ocfg, table, batch, state)  # warm-up (allocations, oneDNN primitive caches)
+        log(f"cpu_baseline[{threads} threads]: warm-up step {time.time() - tw:.1f} s")
+        n, t0 = 0, time.time()
+        while n < 1 or (time.time() - t0 < budget and n < max_steps):
+            orc.train_step(sd, ocfg, table, batch, state)
+            n += 1
+            log(f"cpu_baseline[{threads} threads]: step {n} at {time.time() - t0:.1f} s")
+        return n, time.time() - t0
+
+    n, dt = timed(cores, seconds_budget * 0.6, 5)
+    out = {"value": B * n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+           "sample": f"{n} full fp32 training steps (forward, backward, clip, AdamW) of the CPU oracle at the same model "
+                     f"shape, batch {B} (seq 512, V={ocfg.vocab_size}, K={ocfg.kg_vocab_size}), after one warm-up step; "
+                     f"torch {torch.__version__}, mkldnn {torch.backends.mkldnn.is_available()}, "
+                     f"mkl {torch.backends.mkl.is_available()}"}
+    if cores > 8:
+        n8, dt8 = timed(8, seconds_budget * 0.4, 2)
+        out["at_8_threads"] = {"value": B * n8 / dt8, "cores": 8, "steps": n8}
+    return out
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` with N > 1 outside a launcher: start N ranks (one per GPU, RCCL) through
+    torch.distributed.run as a CHILD process and relay its exit code; rank 0 of the child job prints the JSON line on the
+    inherited stdout. This parent never touches a GPU (a process that has initialised HIP must not be replaced or forked)."""
+    import socket
+    import subprocess
+
+    n_dev = torch.cuda.device_count()   # (does not initialise the HIP runtime)
+    if n_dev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible", file=sys.stderr, flush=True)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"spawning {args.gpus} ranks: {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:   # never report a job of a different size than the one asked for
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr, flush=True)
+        sys.exit(2)
     import torch.distributed as dist
 
     # one rank per GPU over RCCL; STONK_DIST_BACKEND=gloo lets several ranks share one card (a rehearsal of the N > 1
@@ -114,10 +195,13 @@ def main():
     from stonkgs_amd.stonkgs_model import STonKGsForPreTraining
     from stonkgs_amd.stonkgs_pretraining import Trainer, TrainingArguments
 
-    log(f"rank {rank}/{world}: building model")
-    cfg = STonKGsConfig()  # 12L / 768h / 12 heads / 3072 / 512 positions / V 28996 / K 175094, dropout 0.1
+    log(f"rank {rank}/{world}: building model {args.model}")
+    spec = MODELS[args.model]
+    cfg = STonKGsConfig(**spec["cfg"])  # default: 12L / 768h / 12 heads / 3072 / 512 positions / V 28996 / K 175094, dropout 0.1
     model = STonKGsForPreTraining(cfg, seed=0)  # same seed on every rank: replicas start identical (as DDP broadcasts)
     trainer = Trainer(model, TrainingArguments(per_device_train_batch_size=args.batch, max_steps=200, learning_rate=1e-4))
+    if world > 1 and (trainer.world != world or trainer.sync.world != world):
+        raise RuntimeError("gradient synchronizer does not see every rank")
     dev = model.device
     batches = [{k: v.to(dev) for k, v in synthetic_batch(args.batch, cfg.vocab_size, cfg.kg_vocab_size,
                                                          cfg.max_position_embeddings, seed=1234 + rank * 100 + i).items()}
@@ -152,11 +236,13 @@ def main():
 
     roofline = None
     gemm_all = None
+    encoder_path = None
     if not args.no_roofline:
-        # dominant kernel of the step = gemm_tn_w4_kernel (weight + bias gradients of the FFN and fused-QKV linears and the
-        # entity decoder's weight gradient, 37 launches/step; profiles/ has the rocprofv3 kernel-trace of the same command): per-launch HIP events on the
-        # launch stream over two extra steps; achieved = algorithmic FLOPs (2 * M' * N' * tokens per launch) / summed
-        # durations
+        # dominant kernel of the step (rocprofv3 kernel-trace of this same command, profiles/): the weight-gradient GEMM.
+        # Every GEMM launch of two extra steps is bracketed by HIP events ON THE STREAM IT IS LAUNCHED ON, in the launch
+        # configuration the timed steps use (weight gradients on the second stream with their CU share, beside the dgrad
+        # chain): achieved = algorithmic FLOPs (2 * M' * N' * tokens per launch) / summed durations, so the figure is
+        # the in-step one and can be recomputed from the rocprofv3 average of the same kernel
         # (every rank runs the two steps - they contain the gradient all-reduce - and times its own launches; rank 0 reports)
         from stonkgs_amd.engine import GemmTimer
 
@@ -164,41 +250,62 @@ def main():
         for i in range(2):
             trainer.training_step(model, batches[i % len(batches)])
         torch.cuda.synchronize()
-        s = model.engine.gemm_timer.summarize("tn_w4")
-        a = model.engine.gemm_timer.summarize(None)
+        timer = model.engine.gemm_timer
         model.engine.gemm_timer = None
+        kinds = timer.kinds()
+        dom = max(kinds, key=lambda k: timer.summarize(k)["seconds"])
+        s = timer.summarize(dom)
+        a = timer.summarize(None)
         ach = s["flops"] / s["seconds"] / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_tn_w4_kernel (bf16 MFMA 32x32x16, 256x256 tiles over 64-token steps, four "
-                                               "waves, transposed LDS reads, split-K fp32 atomics)",
+        roofline = {"bound": "mfma", "kernel": KERNEL_NOTES.get(dom, dom),
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": TN_W4_TRAFFIC_BYTES,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                    "traffic": TRAFFIC_BYTES.get((args.model, dom)),
                     "traffic_note": "bytes per launch at the L2's memory side = 2 x FETCH_SIZE + WRITE_SIZE (KiB, separate "
-                                    "rocprofv3 --pmc passes over this command, profiles/r01_final_pmc_traffic.csv) against "
-                                    "274 MB of operands + output per launch (36 encoder launches of 243 MB, the entity decoder's 1.39 GB); a recorded constant - counters "
-                                    "cannot be read from inside the bench",
+                                    "rocprofv3 --pmc passes over this command, profiles/) - a recorded constant: counters "
+                                    "cannot be read from inside the bench; null when no pass was taken for this kernel",
+                    "timing": "HIP events around every launch on the stream the step launches it on (second stream, "
+                              "CU share as in the timed steps), two instrumented steps after the timed region",
                     "launches_per_step": s["launches"] // 2,
                     "avg_launch_us": round(s["seconds"] / s["launches"] * 1e6, 1),
-                    "avg_launch_gflop": round(s["flops"] / s["launches"] / 1e9, 2)}
-        gemm_all = {"kernels": "gemm_tn_w4_kernel + gemm_tn_kernel + gemm_nt_kernel + gemm256_kernel", "launches_per_step": a["launches"] // 2,
+                    "avg_launch_gflop": round(s["flops"] / s["launches"] / 1e9, 2),
+                    "by_kernel": {k: {"launches_per_step": timer.summarize(k)["launches"] // 2,
+                                      "ms_per_step": round(timer.summarize(k)["seconds"] / 2 * 1e3, 3),
+                                      "frac": round(timer.summarize(k)["flops"] / max(timer.summarize(k)["seconds"], 1e-12)
+                                                    / 1e12 / PEAK_BF16_TFLOPS, 4)} for k in kinds}}
+        gemm_all = {"kernels": "every GEMM launch of the step (NT forward / dgrad and TN weight-gradient kernels)",
+                    "launches_per_step": a["launches"] // 2,
                     "achieved_tflops": round(a["flops"] / a["seconds"] / 1e12, 1),
                     "frac": round(a["flops"] / a["seconds"] / 1e12 / PEAK_BF16_TFLOPS, 4),
                     "ms_per_step": round(a["seconds"] / 2 * 1e3, 2)}
+        # the attention+FFN path (BASELINE.json's 40 % target): stream-order spans around the trainable encoder's forward
+        # and backward (the backward span ends once that span's weight gradients on the second stream are done; the
+        # decoders' weight gradients still running on that stream at its start are inside it, so this errs low)
+        enc_s = (timer.span_seconds("encoder_fwd") + timer.span_seconds("encoder_bwd")) / 2
+        enc_tf = encoder_gflop_per_pair(cfg) * args.batch / 1e3 / enc_s
+        encoder_path = {"what": "trainable encoder forward + backward (QKV, attention, projections, FFN, LayerNorm, "
+                                "weight gradients), event spans on the main stream over two instrumented steps",
+                        "gflop_per_pair": round(encoder_gflop_per_pair(cfg), 1), "ms_per_step": round(enc_s * 1e3, 2),
+                        "achieved_tflops": round(enc_tf, 1), "frac": round(enc_tf / PEAK_BF16_TFLOPS, 4)}
     if world > 1:
         dist.barrier()
 
     if rank == 0:
         pairs = args.batch * world * args.steps
         value = pairs / dt
+        gfl = gflop_per_pair(cfg)
         out = {"metric": "text-triple pairs/sec (whole node), seq_len=512 hidden=768, 1/2/4/8 MI355X", "value": round(value, 2),
                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "STonKGs-150k pretraining step (12L/768h, V=28996, K=175094), per-GPU batch "
+               "config": {"workload": f"{spec['name']}, per-GPU batch "
                                       f"{args.batch}, seq 256 text + 256 entity, dropout 0.1, AdamW lr 1e-4",
                           "global_batch": args.batch * world, "seq_len": 512, "parallelism": f"dp{world}"},
                "final_loss": round(final_loss, 4),
-               "step_mfma_frac": round(value * GFLOP_PER_PAIR_STEP / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
-               "roofline": roofline, "all_gemm": gemm_all}
+               "gflop_per_pair": round(gfl, 1),
+               "step_mfma_frac": round(value * gfl / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+               "roofline": roofline, "all_gemm": gemm_all,
+               "encoder_path": encoder_path}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)

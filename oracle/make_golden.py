@@ -9,6 +9,7 @@ reference's own ``forward`` / HF BERT / torch AdamW on CPU, and stores inputs + 
 Nothing here runs on the GPU box; the fixtures it writes are data only (ints / floats / config numbers).
 
     python oracle/make_golden.py          # rewrites tests/golden/*.npz, *.json
+    python oracle/make_golden.py shape    # only g3_shapetrue; `f3` = only the TSV / checkpoint cases; `splits` = only g7
 """
 from __future__ import annotations
 
@@ -321,6 +322,176 @@ def splits_case(ft):
     print("splits: plain fold 0 test head:", res["plain_test_0"][:6].tolist())
 
 
+def shape_true_case(name, sm, pre, cfg: orc.OracleConfig, B, seed):
+    """G2 of SURVEY section 8c: the reference's forward / backward at the REAL depth, width and head count
+    (12L / 768h / 12 heads / S = 512, V = 28 996; K = 4 096 keeps the table small). Weights are regenerated from the
+    seed; stored are the batch, the loss terms, sampled outputs and per-tensor gradient norms + sampled gradient slices."""
+    sd = orc.init_state_dict(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    tsv_rows = torch.randn(cfg.kg_vocab_size, cfg.hidden_size, generator=g, dtype=torch.float64) * 0.3
+    model = build_reference_model(sm, cfg, sd, tsv_rows)
+    batch = make_batch(cfg, B, seed + 2, pre)
+    out = model(**batch, return_dict=True)
+    model.zero_grad()
+    out.loss.backward()
+    params = dict(model.named_parameters())
+    arrays = {k: v.numpy() for k, v in batch.items()}
+    with torch.no_grad():
+        tl, el = out.prediction_logits
+        lt = torch.nn.functional.cross_entropy(tl.reshape(-1, cfg.vocab_size), batch["masked_lm_labels"].reshape(-1))
+        le = torch.nn.functional.cross_entropy(el.reshape(-1, cfg.kg_vocab_size), batch["ent_masked_lm_labels"].reshape(-1))
+        ln = torch.nn.functional.cross_entropy(out.seq_relationship_logits, batch["next_sentence_labels"])
+        arrays.update(loss=out.loss.numpy(), masked_lm_loss=lt.numpy(), ent_masked_lm_loss=le.numpy(),
+                      next_sentence_loss=ln.numpy(), nsp_logits=out.seq_relationship_logits.numpy(),
+                      pooler_output=out.pooler_output.numpy(),
+                      hidden_states_s=out.hidden_states[:, ::37, ::11].numpy(),
+                      text_logits_lab_s=tl[batch["masked_lm_labels"] != -100][:, ::97].numpy(),
+                      ent_logits_lab_s=el[batch["ent_masked_lm_labels"] != -100][:, ::29].numpy())
+        for sid in (100, 102, 103):
+            arrays[f"special_{sid}"] = model.kg_backbone[sid].numpy()
+    names = [k for k, p in params.items() if p.grad is not None]
+    arrays["grad_norms"] = np.array([params[k].grad.double().norm().item() for k in names], dtype=np.float64)
+    total_norm = torch.sqrt(sum((params[k].grad.double() ** 2).sum() for k in names))
+    arrays["grad_norm"] = np.float32(total_norm.item())
+    slices = {"bert.encoder.layer.0.attention.self.query.weight": (slice(None, None, 16), slice(None, None, 16)),
+              "bert.encoder.layer.11.intermediate.dense.weight": (slice(None, None, 64), slice(None, None, 16)),
+              "bert.encoder.layer.5.output.dense.weight": (slice(None, None, 16), slice(None, None, 64)),
+              "bert.encoder.layer.6.attention.output.LayerNorm.weight": (slice(None),),
+              "bert.embeddings.position_embeddings.weight": (slice(None, None, 8), slice(None, None, 16)),
+              "cls.predictions.text_decoder.weight": (slice(None, None, 101), slice(None, None, 16)),
+              "cls.predictions.entity_decoder.weight": (slice(None, None, 17), slice(None, None, 16))}
+    for k, sl in slices.items():
+        arrays["grad_s::" + k] = params[k].grad[sl].numpy()
+    meta = {"config": {k: getattr(cfg, k) for k in ("vocab_size", "kg_vocab_size", "hidden_size", "num_hidden_layers",
+                                                    "num_attention_heads", "intermediate_size",
+                                                    "max_position_embeddings", "type_vocab_size", "layer_norm_eps")},
+            "B": B, "weight_seed": seed, "table_seed": seed + 1, "batch_seed": seed + 2, "table_std": 0.3,
+            "weights_checksum": float(sum(v.double().abs().sum() for v in sd.values())),
+            "table_checksum": float(tsv_rows.abs().sum()), "grad_names": names,
+            "grad_slices": {k: [[x.start, x.stop, x.step] for x in sl] for k, sl in slices.items()},
+            "grad_keys": list(slices), "dead_parameters": sorted(k for k, p in params.items() if p.requires_grad and p.grad is None),
+            "torch": torch.__version__}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(name, "loss", float(out.loss), "grad_norm", float(total_norm))
+
+
+def import_reference_prepare_df():
+    """The reference's own TSV reader, ref:src/stonkgs/models/kg_baseline_model.py:270-280, from the real module (the
+    stub installed for importing stonkgs_model is bypassed). Its module-level imports of the experiment-tracking and
+    trainer frameworks (absent here, used by the KG-baseline classes only) are given empty stand-in modules."""
+    import importlib.util
+
+    for mod, attrs in (("mlflow", {}), ("pytorch_lightning", {"LightningModule": torch.nn.Module, "LightningDataModule": object})):
+        if mod not in sys.modules:
+            m = types.ModuleType(mod)
+            for k, v in attrs.items():
+                setattr(m, k, v)
+            sys.modules[mod] = m
+    const = sys.modules["stonkgs.constants"]
+    for k in ("KG_BL_OUTPUT_DIR",):
+        setattr(const, k, "/nonexistent/" + k)
+    spec = importlib.util.spec_from_file_location("stonkgs.models._kg_baseline_real", REF + "/models/kg_baseline_model.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.prepare_df
+
+
+def table_case(prepare_df_ref):
+    """G8 (row f3): node2vec TSVs as the reference reads them. g8_table.tsv - 120 named nodes x 128 dims, values written
+    with 17 significant digits (pins the float parser), names of the kinds the real file holds; g8_numeric.tsv - an
+    all-numeric first column, which pandas turns into an integer index. Expected: key list (with type) and fp64 values."""
+    rng = np.random.RandomState(11)
+    names = [f"HGNC:{i * 37 + 5}" for i in range(54)] + [f"CHEBI:{i * 101 + 3}" for i in range(30)] + \
+            [f"MESH:D{i * 977 + 1:06d}" for i in range(28)] + ["p(HGNC:AKT1)", "a b", "GO:0006915", "7157", "1e5",
+                                                               "NaN_node", "x" * 40, "FPLX:ERK"]
+    assert len(set(names)) == 120     # (the reference's index construction needs K + 3 > 103, ref:stonkgs_model.py:126-127)
+    vals = rng.randn(120, 128) * 0.3
+    vals[0, :4] = [1e-310, -0.0, 3.0, 1e5]   # a subnormal, a signed zero, integers written without a fraction
+    path = os.path.join(OUT, "g8_table.tsv")
+    with open(path, "w") as fh:
+        for n, v in zip(names, vals):
+            fh.write(n + "\t" + "\t".join(repr(float(x)) if float(x) != int(x) or abs(x) > 1e15 else str(int(x)) for x in v) + "\n")
+    d = prepare_df_ref(path)
+    npath = os.path.join(OUT, "g8_numeric.tsv")
+    ids = [900, 17, 100, 102, 5]
+    nvals = rng.randn(5, 4)
+    with open(npath, "w") as fh:
+        for i, v in zip(ids, nvals):
+            fh.write(str(i) + "\t" + "\t".join(repr(float(x)) for x in v) + "\n")
+    dn = prepare_df_ref(npath)
+    res = {"keys": np.array([str(k) for k in d.keys()]), "key_types": np.array([type(k).__name__ for k in d.keys()]),
+           "values": np.stack([np.asarray(v, dtype=np.float64) for v in d.values()]),
+           "value_dtype": np.array(str(next(iter(d.values())).dtype)),
+           "num_keys": np.array([int(k) for k in dn.keys()], dtype=np.int64),
+           "num_key_types": np.array([type(k).__name__ for k in dn.keys()]),
+           "num_values": np.stack([np.asarray(v, dtype=np.float64) for v in dn.values()])}
+    np.savez_compressed(os.path.join(OUT, "g8_table.npz"), **res)
+    print("table: first key", res["keys"][0], res["key_types"][0], "| numeric keys", res["num_keys"].tolist(), res["num_key_types"][0])
+
+
+def checkpoint_case(sm, pre, prepare_df_ref):
+    """G9 (row f3): a checkpoint directory WRITTEN BY THE REFERENCE-SIDE MODEL with HF's own `save_pretrained`
+    (config.json + model.safetensors, tied / dead aliases dropped as safetensors does) for the smallest shape the HIP
+    path supports with one layer, on the 120-node table of G8; plus a local LM-backbone directory written by HF
+    `BertModel.save_pretrained` (what `nlp_model_type=<dir>` reads); plus the reference's outputs on one batch."""
+    import shutil
+
+    from transformers import BertConfig, BertModel
+
+    cfg = orc.OracleConfig(vocab_size=160, kg_vocab_size=120, hidden_size=128, num_hidden_layers=1, num_attention_heads=2,
+                           intermediate_size=256, max_position_embeddings=256)
+    seed = 400
+    sd = orc.init_state_dict(cfg, seed=seed)
+    d = prepare_df_ref(os.path.join(OUT, "g8_table.tsv"))
+    tsv_rows = torch.from_numpy(np.stack(list(d.values())))
+    model = build_reference_model(sm, cfg, sd, tsv_rows)
+    batch = make_batch(cfg, 3, seed + 2, pre)
+    out = model(**batch, return_dict=True)
+    ck = os.path.join(OUT, "g9_ref_checkpoint")
+    shutil.rmtree(ck, ignore_errors=True)
+    kg = model.kg_backbone
+    # The writer: transformers 5.x refuses to serialise this model at all (its safetensors path finds the reference's
+    # undeclared aliases decoder.text_bias / decoder.entity_bias and raises), so the directory is written the way the
+    # transformers the reference pins (>= 4.6.1; the published stonkgs checkpoints are config.json + pytorch_model.bin,
+    # ref:src/stonkgs/api/api.py:96-101) wrote it: config.save_pretrained + torch.save(model.state_dict()).
+    os.makedirs(ck)
+    model.config.save_pretrained(ck)
+    torch.save(model.state_dict(), os.path.join(ck, "pytorch_model.bin"))
+    # ... and the key set a safetensors writer keeps for the same model (safetensors' own shared-tensor handling)
+    import tempfile
+
+    from safetensors import safe_open
+    from safetensors.torch import save_model
+
+    with tempfile.TemporaryDirectory() as tmp:
+        save_model(model, os.path.join(tmp, "model.safetensors"))
+        with safe_open(os.path.join(tmp, "model.safetensors"), "pt") as f:
+            keys = sorted(f.keys())
+    bb = os.path.join(OUT, "g9_lm_backbone")
+    shutil.rmtree(bb, ignore_errors=True)
+    model.lm_backbone.save_pretrained(bb)   # HF's own writer for a plain BertModel: config.json + model.safetensors
+    arrays = {k: v.numpy() for k, v in batch.items()}
+    with torch.no_grad():
+        arrays.update(loss=out.loss.numpy(), pooler_output=out.pooler_output.numpy(),
+                      nsp_logits=out.seq_relationship_logits.numpy(),
+                      ent_logits_lab=out.prediction_logits[1][batch["ent_masked_lm_labels"] != -100].numpy(),
+                      table_row_7=kg[7].numpy(), table_row_101=kg[101].numpy(), table_row_104=kg[104].numpy(),
+                      special_102=kg[102].numpy())
+    np.savez_compressed(os.path.join(OUT, "g9_ref_checkpoint.npz"), **arrays)
+    with open(os.path.join(OUT, "g9_ref_checkpoint.json"), "w") as f:
+        json.dump({"weight_seed": seed, "safetensors_keys": keys, "state_dict_keys": sorted(model.state_dict().keys()),
+                   "files": sorted(os.listdir(ck)),
+                   "backbone_files": sorted(os.listdir(bb)), "idx_to_name_head": {str(i): str(model_name) for i, model_name in
+                                                                                   list(zip([i for i in range(123) if i not in (100, 102, 103)], d.keys()))[98:104]},
+                   "config": {k: getattr(cfg, k) for k in ("vocab_size", "kg_vocab_size", "hidden_size", "num_hidden_layers",
+                                                           "num_attention_heads", "intermediate_size",
+                                                           "max_position_embeddings", "type_vocab_size", "layer_norm_eps")}},
+                  f, indent=1, sort_keys=True)
+    print("checkpoint:", len(keys), "tensors;", sorted(os.listdir(ck)), "loss", float(out.loss))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "splits":     # only (re)generate G7
@@ -330,6 +501,16 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
     sm, pre = import_reference()
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only in ("shape", "f3"):   # (re)generate only the round-2 cases
+        if only == "shape":
+            torch.set_num_threads(8)
+            shape_true_case("g3_shapetrue", sm, pre, orc.OracleConfig(kg_vocab_size=4096), B=2, seed=500)
+        else:
+            pdf = import_reference_prepare_df()
+            table_case(pdf)
+            checkpoint_case(sm, pre, pdf)
+        return
     # G1: tiny, every tensor stored (pins the oracle op for op)
     model_case("g1_tiny", sm, pre, orc.OracleConfig(vocab_size=300, kg_vocab_size=150, hidden_size=64, num_hidden_layers=2,
                                                    num_attention_heads=4, intermediate_size=128,
@@ -346,6 +527,12 @@ def main():
                                          num_attention_heads=2, intermediate_size=256, max_position_embeddings=256),
                         B=5, seed=300, num_labels=3)
     splits_case(ft)
+    # round 2: the shape-true case (12L / 768h / 12 heads / S = 512), TSV ingestion, a reference-written checkpoint
+    torch.set_num_threads(8)
+    shape_true_case("g3_shapetrue", sm, pre, orc.OracleConfig(kg_vocab_size=4096), B=2, seed=500)
+    pdf = import_reference_prepare_df()
+    table_case(pdf)
+    checkpoint_case(sm, pre, pdf)
 
 
 if __name__ == "__main__":

@@ -297,7 +297,7 @@ class AdamState:
 
 def train_step(sd: Dict[str, Tensor], cfg: OracleConfig, kg_table: Tensor, batch: Dict[str, Tensor], state: AdamState,
                base_lr: float = 1e-4, max_steps: int = 200, max_grad_norm: float = 1.0, betas=(0.9, 0.999),
-               eps: float = 1e-8, weight_decay: float = 0.0) -> Dict[str, Tensor]:
+               eps: float = 1e-8, weight_decay: float = 0.0, return_outputs: bool = False) -> Dict[str, Tensor]:
     """One Trainer optimizer step (forward, backward, clip, AdamW, schedule); updates `sd` in place.
     Returns loss terms, the pre-clip global grad norm and the gradients (for parity checks)."""
     names = trainable_names(sd)
@@ -326,6 +326,8 @@ def train_step(sd: Dict[str, Tensor], cfg: OracleConfig, kg_table: Tensor, batch
             p.addcdiv_(m, denom, value=-lr / bc1)
     res = {k: out[k].detach() for k in ("loss", "masked_lm_loss", "ent_masked_lm_loss", "next_sentence_loss")}
     res.update(grad_norm=total_norm, lr=lr, grads=grads)
+    if return_outputs:
+        res["outputs"] = {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
     return res
 
 

@@ -34,6 +34,14 @@ class GemmTimer:
 
     def __init__(self):
         self.records = []  # (kind, start_event, end_event, M, N, K, m_dev, k_dev)
+        self.spans = {}    # name -> [(start_event, end_event)]: stream-order spans (the encoder's forward / backward)
+
+    def kinds(self):
+        return sorted({r[0] for r in self.records})
+
+    def span_seconds(self, name) -> float:
+        torch.cuda.synchronize()
+        return sum(s.elapsed_time(e) for s, e in self.spans.get(name, [])) * 1e-3
 
     def summarize(self, kind=None):
         """Algorithmic FLOPs use the rows / contraction length that exist at run time (device-side counts of the
@@ -96,6 +104,13 @@ class Engine:
         self._opt_stream: Optional[torch.cuda.Stream] = None
         self._params_ready: Optional[torch.cuda.Event] = None
         self._wgrad_done: Dict[int, torch.cuda.Event] = {}   # layer parity -> side-stream event after its last wgrad
+        # development switches, read ONCE here (tools/ab_step.py builds a fresh engine per arm): the 128x128 weight-gradient
+        # kernel everywhere / the CU share of the side-stream weight gradients / the 768 x 768 gradients on the four-wave
+        # kernel as well / QKV and backbone FFN-up forward on the four-wave kernel
+        self.tn_v1 = bool(os.environ.get("STONK_TN_V1"))
+        self.tn_cus = int(os.environ.get("STONK_TN_CUS", "160"))
+        self.tn_min_tiles = 36 if os.environ.get("STONK_TN_SMALL") else 100
+        self.fwd_w4 = bool(os.environ.get("STONK_FWD_W4"))
 
     # ------------------------------------------------------------------ plumbing
     def buf(self, name: str, shape, dtype=BF16, zero=False) -> torch.Tensor:
@@ -131,6 +146,20 @@ class Engine:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
+    def _span_begin(self):
+        """(GemmTimer only) start of a stream-order span on the current stream."""
+        if self.gemm_timer is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _span_end(self, name, start) -> None:
+        if start is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.gemm_timer.spans.setdefault(name, []).append((start, e))
+
     def ln_ws(self) -> torch.Tensor:
         """Partial-sum workspace of the LayerNorm backward kernels (1024 workgroups x 2H floats)."""
         return self.buf("ln.ws", (1024 * 2 * self.cfg.hidden_size,), F32)
@@ -161,8 +190,7 @@ class Engine:
             e1.record()
             self.gemm_timer.records.append(("nt", e0, e1, M, N, K, m_dev, k_dev))
 
-    @staticmethod
-    def _split_k(M, N, K, side_stream=False) -> int:
+    def _split_k(self, M, N, K, side_stream=False) -> int:
         # 128x128 tiles, two workgroups co-resident per CU = 512 slots on 256 CUs: the sweep in tools/sweep_wgrad.py
         # is fastest when tiles x split fills ONE co-resident wave without a tail (432-480 workgroups)
         tiles = ((M + 127) // 128) * (N // 128)
@@ -172,35 +200,32 @@ class Engine:
         # stream) the kernel is held to 160 CUs' worth of workgroups (split_k = -160): another -1.5 ms
         # ... and so does the entity decoder's 175 104 x 768 gradient (2052 unsplit tiles, device-side token count, 5.7 GB
         # operand extent - the kernel re-bases its buffer resources per K tile): 863 us against 966 alone, -0.27 ms in the step
-        min_tiles = 36 if os.environ.get("STONK_TN_SMALL") else 100   # (A/B: the 768 x 768 gradients as well)
-        if tiles >= min_tiles and K >= 16384 and M % 256 == 0 and N % 256 == 0 and not os.environ.get("STONK_TN_V1"):
-            return -int(os.environ.get("STONK_TN_CUS", "160")) if side_stream else 0
+        if tiles >= self.tn_min_tiles and K >= 16384 and M % 256 == 0 and N % 256 == 0 and not self.tn_v1:
+            return -self.tn_cus if side_stream else 0
         return max(1, min(32, 480 // tiles, K // 64))
 
     def wgrad(self, dy, x, dW, db, M_out, N_in, T, k_dev=None, alpha=1.0):
-        """dW[M_out, N_in] += dy[T, M_out]^T . x[T, N_in];  db[M_out] += colsum(dy)   (fp32 atomics, split-K)."""
-        if self.overlap_wgrad and self.gemm_timer is None:
+        """dW[M_out, N_in] += dy[T, M_out]^T . x[T, N_in];  db[M_out] += colsum(dy)   (fp32 atomics, split-K).
+        With `overlap_wgrad` the launch goes to the second stream, ordered after everything enqueued so far on the
+        current one; a GemmTimer brackets it with events on THAT stream, in the same launch configuration."""
+        side = self.overlap_wgrad
+        split = self._split_k(M_out, N_in, T, side)
+        timed = self.gemm_timer is not None
+        if side:
             if self._wstream is None:
                 self._wstream = torch.cuda.Stream(device=self.device)
             ready = torch.cuda.Event()
             ready.record()                       # dy (and x) are complete on the main stream at this point
             self._wstream.wait_event(ready)
-            with torch.cuda.stream(self._wstream):
-                hip.call("stonk_gemm_tn_bf16", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(),
-                         dW.stride(0), hip.ptr(db), M_out, N_in, T, alpha, self._split_k(M_out, N_in, T, True),
-                         hip.ptr(k_dev), hip.stream_ptr())
-            return
-        timed = self.gemm_timer is not None
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        hip.call("stonk_gemm_tn_bf16", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(),
-                 dW.stride(0), hip.ptr(db), M_out, N_in, T, alpha, self._split_k(M_out, N_in, T), hip.ptr(k_dev),
-                 hip.stream_ptr())
-        if timed:
-            e1.record()
-            kind = "tn_w4" if self._split_k(M_out, N_in, T) == 0 else "tn"
-            self.gemm_timer.records.append((kind, e0, e1, M_out, N_in, T, None, k_dev))
+        with (torch.cuda.stream(self._wstream) if side else contextlib.nullcontext()):
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            hip.call("stonk_gemm_tn_bf16", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dW.data_ptr(),
+                     dW.stride(0), hip.ptr(db), M_out, N_in, T, alpha, split, hip.ptr(k_dev), hip.stream_ptr())
+            if timed:
+                e1.record()
+                self.gemm_timer.records.append(("tn_w4" if split <= 0 else "tn", e0, e1, M_out, N_in, T, None, k_dev))
 
     def transpose(self, x, rows, cols, name, colsum=None, rows_dev=None):
         rpad = (rows + 63) // 64 * 64
@@ -243,7 +268,7 @@ class Engine:
         w = S.bf16_view
         f = S.view
         qkv = self.buf(f"{tag}.qkv", (T, 3 * H))
-        w4 = hip.EPI_DEBUG_W4 if os.environ.get("STONK_FWD_W4") else 0   # (development switch, tools/fwd_w4_probe.py)
+        w4 = hip.EPI_DEBUG_W4 if self.fwd_w4 else 0   # (development switch, tools/fwd_w4_probe.py)
         self.gemm(x, w(prefix + ".attention.self.qkv.weight"), qkv, T, 3 * H, H, flags=hip.EPI_BIAS | w4,
                   bias=f(prefix + ".attention.self.qkv.bias"))
         ctx = self.buf(f"{tag}.ctx", (T, H))
@@ -352,7 +377,7 @@ class Engine:
         self.gemm(dqkv, wt[prefix + ".attention.self.qkv.weight"], dx, T, H, 3 * H,
                   flags=hip.EPI_RESID | (hip.EPI_DEBUG_W4 if self.w4_dgrad_resid and not self.comm_overlap else 0),
                   resid=ds1)
-        if self._wstream is not None and self.overlap_wgrad and self.gemm_timer is None:
+        if self._wstream is not None and self.overlap_wgrad:
             done = torch.cuda.Event()
             done.record(self._wstream)
             self._wgrad_done[par] = done
@@ -417,8 +442,10 @@ class Engine:
                  self.kg_table.shape[0], cfg.type_vocab_size, cfg.layer_norm_eps, hip.LN_DROPOUT if p_hid > 0 else 0,
                  p_hid, self.seed(200, 0), self.err.data_ptr(), st)
         # F3 encoder
+        span = self._span_begin()
         for i in range(cfg.num_hidden_layers):
             x = self.layer_fwd(P, f"bert.encoder.layer.{i}", x, B, S, attention_mask, p_hid, p_att, i, save)
+        self._span_end("encoder_fwd", span)
         seq_out = x
         # F4 pooler (fp32 master weights)
         pooled = self.buf("h.pooled", (B, H), F32)
@@ -616,10 +643,14 @@ class Engine:
         notify("bert.pooler.dense.bias")
         # ---- encoder layers, last to first
         dy = dseq
+        span = self._span_begin()
         for i in reversed(range(cfg.num_hidden_layers)):
             prefix = f"bert.encoder.layer.{i}"
             dy = self.layer_bwd(prefix, dy, B, S, sv["attention_mask"], sv["p_hid"], sv["p_att"], i, sv[prefix])
             notify(prefix)
+        if span is not None and self._wstream is not None:   # (timing only) the span ends when the layers' weight gradients have
+            torch.cuda.current_stream().wait_stream(self._wstream)
+        self._span_end("encoder_bwd", span)
         # ---- embeddings LayerNorm, position / token-type embeddings
         dsum = self.buf("b.dsum0", (T, H))
         p_hid = sv["p_hid"]

@@ -29,6 +29,10 @@ from .params import (FlatStore, _Node, _linear, _param, backbone_specs, build_be
                      trainable_specs)
 
 SEP_ID, MASK_ID, UNK_ID = 102, 103, 100  # BioBERT vocabulary (ref:stonkgs_model.py:116-118)
+# state-dict keys a checkpoint may lack (see from_pretrained)
+_DROPPED_ALIASES = ("position_ids", "cls.predictions.decoder.", "cls.predictions.bias", "cls.predictions.text_bias",
+                    "cls.predictions.entity_bias", "bert.embeddings.word_embeddings.weight")
+_FRESH_HEAD_PREFIXES = ("classifier.",)
 
 
 @dataclass
@@ -50,18 +54,15 @@ class BertForPreTrainingOutputWithPooling:
         return getattr(self, k) if isinstance(k, str) else self.to_tuple()[k]
 
 
-def prepare_df(embedding_path: str, sep: str = "\t") -> Dict[str, "object"]:
-    """ref:src/stonkgs/models/kg_baseline_model.py:270-280: TSV (index column = node name, no header) ->
-    {name: float64 vector}, in file order."""
-    import numpy as np
+def prepare_df(embedding_path: str, sep: str = "\t") -> Dict[object, "object"]:
+    """ref:src/stonkgs/models/kg_baseline_model.py:270-280: TSV (first column = node name, no header) ->
+    {name: float64 vector}, in file order. Read with pandas like the reference, so that the parsed values (its C
+    float parser) and the key types (an all-numeric name column becomes an integer index) are the reference's:
+    pinned by tests/golden/g8_table.* made with the reference's own function."""
+    import pandas as pd
 
-    out: Dict[str, object] = {}
-    with open(embedding_path) as fh:
-        for line in fh:
-            parts = line.rstrip("\n").split(sep)
-            if len(parts) > 1:
-                out[parts[0]] = np.asarray([float(x) for x in parts[1:]], dtype=np.float64)
-    return out
+    df = pd.read_csv(embedding_path, sep=sep, header=None, index_col=0)
+    return dict(zip(df.index.tolist(), df.to_numpy()))   # (= {index: row.values for index, row in df.iterrows()})
 
 
 class KGBackbone:
@@ -121,8 +122,10 @@ class _StepFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         model = ctx.model
+        model._prepare_grads_for_autograd()
         model.engine.backward(float(dloss), model._segment_hook)
         model._reattach_grads()
+        model._external_step_pending = True   # whoever called loss.backward() steps the masters with its own optimizer
         return None, None, None
 
 
@@ -242,6 +245,56 @@ class STonKGsForPreTraining(nn.Module):
             if sid < K + 3:
                 table[sid] = vec
         self.kg_backbone = KGBackbone(table)
+        self._mark_synced()
+
+    # -------------------------------------------------------------- masters <-> derived copies
+    # The GEMMs read bf16 mirrors and bf16 W^T copies of the fp32 master weights; the fused optimizer refreshes them itself.
+    # Anything ELSE that writes the masters (a torch optimizer stepping the nn.Parameters after loss.backward(), a manual
+    # `p.data.copy_`, `load_state_dict`) is noticed here: in-place writes through the parameters bump the version counter
+    # their flat buffer shares with them, and an autograd-driven backward sets `_external_step_pending` (covers writers
+    # that go through `.data`, which has a version counter of its own).
+    def _mark_synced(self) -> None:
+        self._synced_versions = (self._store.data._version, self._bb_store.data._version,
+                                 self._heads_store.data._version)
+        self._external_step_pending = False
+
+    def _sync_derived(self) -> None:
+        """Called at the top of every forward: bring the bf16 mirrors / W^T copies (and, if the frozen backbone was
+        written, the entity table's LM special rows) up to date with externally modified master weights."""
+        v = (self._store.data._version, self._bb_store.data._version, self._heads_store.data._version)
+        if v == self._synced_versions and not self._external_step_pending:
+            return
+        self._wait_params()
+        if v[1] != self._synced_versions[1]:
+            self.refresh()              # backbone changed: special vectors of the entity table too (quirk Q2)
+        else:
+            self.engine.refresh_derived(bf16_mirror=True)
+            self._mark_synced()
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        """nn.Module.zero_grad on the flat gradient buffer: the engine's backward ACCUMULATES into it (+= / atomics), so
+        dropping the `.grad` attributes alone would leave last step's gradients in place. The buffer is zeroed for both
+        values of `set_to_none`; with True the attributes are dropped as torch does and re-attached by the next backward."""
+        self._wait_params()
+        self._store.grad.zero_()
+        for p in self.parameters():
+            if p.requires_grad:
+                p.grad = None if set_to_none else p.grad
+        if not set_to_none:
+            self._reattach_grads(force=True)
+
+    def _prepare_grads_for_autograd(self) -> None:
+        """torch semantics for `loss.backward()`: a parameter whose `.grad` is None starts from zero (an optimizer's
+        zero_grad(set_to_none=True) only drops the attributes), one that still has its view accumulates."""
+        params = [(n, p) for n, p in nn.Module.named_parameters(self) if p.requires_grad]
+        dropped = [n for n, p in params if p.grad is None]
+        if not dropped:
+            return
+        if len(dropped) == len(params):
+            self._store.grad.zero_()
+        else:
+            for n in dropped:
+                self._grad_views[n].zero_()
 
     # -------------------------------------------------------------- nn.Module plumbing
     @property
@@ -277,12 +330,9 @@ class STonKGsForPreTraining(nn.Module):
             self.refresh()
         return res
 
-    def _reattach_grads(self) -> None:
-        first = self.cls.predictions.entity_decoder.weight
-        if first.grad is not None:
-            return
-        for name, p in self.named_parameters():
-            if p.requires_grad and p.grad is None:
+    def _reattach_grads(self, force: bool = False) -> None:
+        for name, p in nn.Module.named_parameters(self):
+            if p.requires_grad and (force or p.grad is None):
                 p.grad = self._grad_views[name]
 
     def named_grad_views(self) -> Dict[str, torch.Tensor]:
@@ -302,9 +352,20 @@ class STonKGsForPreTraining(nn.Module):
         if sd is None:
             raise FileNotFoundError(f"no pytorch_model.bin / model.safetensors under {path!r}")
         missing, unexpected = model.load_state_dict(sd, strict=False)
-        bad = [k for k in missing if "position_ids" not in k]
+        # what HF's from_pretrained tolerates for this architecture: buffers that are not parameters here, the tied / dead
+        # aliases a safetensors checkpoint drops (quirk Q4: word_embeddings <-> cls.predictions.decoder.weight,
+        # cls.predictions.bias <-> decoder.bias, text_bias / entity_bias <-> decoder.*), and the heads the checkpoint's
+        # architecture does not have - `STonKGsForSequenceClassification.from_pretrained(pretraining_dir, num_labels=n)`
+        # (ref:stonkgs_finetuning.py:404-407) keeps the freshly initialised classifier, as HF does, and says so
+        fresh = [k for k in missing if k.startswith(_FRESH_HEAD_PREFIXES)]
+        bad = [k for k in missing if k not in fresh and not any(t in k for t in _DROPPED_ALIASES)]
         if bad:
             raise KeyError(f"checkpoint misses {bad[:5]}...")
+        if fresh:
+            import warnings
+
+            warnings.warn(f"Some weights of {cls.__name__} were not initialized from the checkpoint at {path} and are "
+                          f"newly initialized: {fresh}. You should probably TRAIN this model on a down-stream task.")
         return model
 
     @classmethod
@@ -352,6 +413,7 @@ class STonKGsForPreTraining(nn.Module):
             raise ValueError(f"input_ids must be [B, {cfg.max_position_embeddings}] (text half | entity half)")
         have_labels = mlm is not None and elm is not None and nsp is not None
         training = self.training
+        self._sync_derived()
         need_bwd = have_labels and torch.is_grad_enabled() and training
         dense = self.materialize_logits if self.materialize_logits is not None else not training
         out = self.engine.forward(input_ids, attention_mask, token_type_ids, mlm if have_labels else None,
@@ -393,6 +455,7 @@ class STonKGsForPreTraining(nn.Module):
         input_ids, attention_mask, token_type_ids = prep(input_ids), prep(attention_mask), prep(token_type_ids)
         if input_ids.dim() != 2 or input_ids.shape[1] != cfg.max_position_embeddings:
             raise ValueError(f"input_ids must be [B, {cfg.max_position_embeddings}] (text half | entity half)")
+        self._sync_derived()
         seq_out, pooled = self.engine.encode(input_ids, attention_mask, token_type_ids, False, None)
         self.engine.check_errors()
         B = input_ids.shape[0]
@@ -406,6 +469,7 @@ class STonKGsForPreTraining(nn.Module):
         dev = self._device
         t = {k: (v if (torch.is_tensor(v) and v.device == dev and v.dtype == torch.long and v.is_contiguous())
                  else torch.as_tensor(v).to(device=dev, dtype=torch.long).contiguous()) for k, v in inputs.items()}
+        self._sync_derived()
         out = self.engine.forward(t["input_ids"], t.get("attention_mask"), t.get("token_type_ids"),
                                   t["masked_lm_labels"], t["ent_masked_lm_labels"], t["next_sentence_labels"],
                                   self.training, False, True)
@@ -438,8 +502,10 @@ class _ClsStepFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         model = ctx.model
+        model._prepare_grads_for_autograd()
         model.engine.backward_cls(float(dloss), model._segment_hook)
         model._reattach_grads()
+        model._external_step_pending = True
         return None, None, None
 
 
@@ -499,6 +565,7 @@ class STonKGsForSequenceClassification(STonKGsForPreTraining):
         self._check_problem_type(labels)
         ids, am, tt, lab = self._prep(input_ids), self._prep(attention_mask), self._prep(token_type_ids), self._prep(labels)
         training = self.training
+        self._sync_derived()
         need_bwd = lab is not None and torch.is_grad_enabled() and training
         out = self.engine.forward_cls(ids, am, tt, lab, self.num_labels, training, need_bwd)
         loss = None
@@ -512,6 +579,7 @@ class STonKGsForSequenceClassification(STonKGsForPreTraining):
     def forward_backward(self, inputs, gscale: float = 1.0, on_segment_done=None):
         labels = inputs.get("labels")
         self._check_problem_type(labels)
+        self._sync_derived()
         out = self.engine.forward_cls(self._prep(inputs["input_ids"]), self._prep(inputs.get("attention_mask")),
                                       self._prep(inputs.get("token_type_ids")), self._prep(labels), self.num_labels,
                                       self.training, True)

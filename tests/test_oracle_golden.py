@@ -159,3 +159,67 @@ def test_masking_oracle_properties():
     for b in range(6):
         if nsp[b] == 0:
             assert np.array_equal(a[b, 32:47], walks[b]) and np.array_equal(a[b, 48:63], walks[b + 3])
+
+
+def _slice_of(spec):
+    return tuple(slice(a, b, c) for a, b, c in spec)
+
+
+def test_shape_true_case_matches_reference():
+    """SURVEY section 8c's G2 at the real depth / width / head count (12L, 768h, 12 heads, S = 512, V = 28 996; K = 4 096):
+    the oracle against the reference's own forward and backward - loss terms, sampled outputs, the global gradient norm,
+    the norm of EVERY gradient tensor and sampled slices of seven of them."""
+    cfg, sd, tsv_rows, batch, gold, meta = load_case("g3_shapetrue")
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        table = _table(cfg, sd, tsv_rows)
+        for sid in (100, 102, 103):
+            np.testing.assert_allclose(table[sid].numpy(), gold[f"special_{sid}"], rtol=1e-4, atol=1e-5)
+    res = orc.train_step({k: v.clone() for k, v in sd.items()}, cfg, table, batch, orc.AdamState(), max_grad_norm=0.0,
+                         return_outputs=True)
+    for k in ("loss", "masked_lm_loss", "ent_masked_lm_loss", "next_sentence_loss"):
+        assert abs(float(res[k]) - float(gold[k])) <= 2e-5, k
+    out = res["outputs"]
+    np.testing.assert_allclose(out["pooler_output"].numpy(), gold["pooler_output"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["nsp_logits"].numpy(), gold["nsp_logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["hidden_states"][:, ::37, ::11].numpy(), gold["hidden_states_s"], rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(out["text_logits"][batch["masked_lm_labels"] != -100][:, ::97].numpy(),
+                               gold["text_logits_lab_s"], rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(out["ent_logits"][batch["ent_masked_lm_labels"] != -100][:, ::29].numpy(),
+                               gold["ent_logits_lab_s"], rtol=1e-3, atol=2e-5)
+    assert abs(float(res["grad_norm"]) - float(gold["grad_norm"])) <= 1e-4 * float(gold["grad_norm"])
+    assert set(meta["grad_names"]) == set(orc.trainable_names(sd))
+    for name, ref_norm in zip(meta["grad_names"], gold["grad_norms"]):
+        got = float(res["grads"][name].double().norm())
+        assert abs(got - ref_norm) <= 2e-4 * ref_norm + 1e-7, name
+    for k in meta["grad_keys"]:
+        np.testing.assert_allclose(res["grads"][k][_slice_of(meta["grad_slices"][k])].numpy(), gold["grad_s::" + k],
+                                   rtol=1e-3, atol=2e-6, err_msg=k)
+
+
+def test_reference_written_checkpoint_and_tsv_table():
+    """Row f3 on the oracle side: the state dict the reference-side model wrote (tests/golden/g9_ref_checkpoint, HF layout)
+    and the node2vec TSV as the reference's prepare_df read it (g8_table.*) reproduce the reference's outputs."""
+    import json
+    import os
+
+    gold = dict(np.load(os.path.join(GOLDEN, "g9_ref_checkpoint.npz")))
+    meta = json.load(open(os.path.join(GOLDEN, "g9_ref_checkpoint.json")))
+    tab = dict(np.load(os.path.join(GOLDEN, "g8_table.npz")))
+    cfg = orc.OracleConfig(**meta["config"])
+    sd = torch.load(os.path.join(GOLDEN, "g9_ref_checkpoint", "pytorch_model.bin"), map_location="cpu", weights_only=True)
+    assert sorted(sd.keys()) == meta["state_dict_keys"]
+    seeded = orc.init_state_dict(cfg, seed=meta["weight_seed"])
+    for k, v in seeded.items():
+        assert torch.equal(sd[k], v), k    # the reference-side writer stored exactly the seeded weights, under HF's names
+    tsv_rows = torch.from_numpy(tab["values"])
+    with torch.no_grad():
+        table = _table(cfg, sd, tsv_rows)
+        batch = {k: torch.from_numpy(gold[k]) for k in ("input_ids", "attention_mask", "token_type_ids", "masked_lm_labels",
+                                                        "ent_masked_lm_labels", "next_sentence_labels")}
+        out = orc.forward(sd, cfg, table, **batch)
+    assert abs(float(out["loss"]) - float(gold["loss"])) <= 1e-5
+    np.testing.assert_allclose(out["pooler_output"].numpy(), gold["pooler_output"], rtol=1e-5, atol=1e-5)
+    for e in (7, 101, 104):        # quirk Q1 through the TSV: id 101 -> row 100, id 104 -> row 101
+        np.testing.assert_array_equal(table[e].numpy(), gold[f"table_row_{e}"].astype(np.float32))
+    np.testing.assert_allclose(table[102].numpy(), gold["special_102"], rtol=1e-5, atol=2e-6)

@@ -24,10 +24,7 @@ torch.cuda.synchronize()
 res = {True: [], False: []}
 for rnd in range(6):
     for val in (True, False):
-        if val:
-            os.environ["STONK_FWD_W4"] = "1"
-        else:
-            os.environ.pop("STONK_FWD_W4", None)
+        model.engine.fwd_w4 = val
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(10):

@@ -447,6 +447,10 @@ def checkpoint_case(sm, pre, prepare_df_ref):
     d = prepare_df_ref(os.path.join(OUT, "g8_table.tsv"))
     tsv_rows = torch.from_numpy(np.stack(list(d.values())))
     model = build_reference_model(sm, cfg, sd, tsv_rows)
+    # the constructor the harness bypasses ends in post_init(), which ties cls.predictions.decoder.weight to the word
+    # embeddings (tie_word_embeddings, hf BertForPreTraining._tied_weights_keys): a checkpoint of the reference has them equal
+    model.tie_weights()
+    assert model.cls.predictions.decoder.weight is model.bert.embeddings.word_embeddings.weight
     batch = make_batch(cfg, 3, seed + 2, pre)
     out = model(**batch, return_dict=True)
     ck = os.path.join(OUT, "g9_ref_checkpoint")

@@ -33,6 +33,7 @@ SEP_ID, MASK_ID, UNK_ID = 102, 103, 100  # BioBERT vocabulary (ref:stonkgs_model
 _DROPPED_ALIASES = ("position_ids", "cls.predictions.decoder.", "cls.predictions.bias", "cls.predictions.text_bias",
                     "cls.predictions.entity_bias", "bert.embeddings.word_embeddings.weight")
 _FRESH_HEAD_PREFIXES = ("classifier.",)
+_TERM_KEYS = ("masked_lm_loss", "ent_masked_lm_loss", "next_sentence_loss")
 
 
 @dataclass
@@ -421,8 +422,7 @@ class STonKGsForPreTraining(nn.Module):
         total_loss = None
         if have_labels:
             total_loss = out["loss"]
-            self.last_loss_terms = tuple(out[k].clone() for k in ("masked_lm_loss", "ent_masked_lm_loss",
-                                                                   "next_sentence_loss"))
+            self.last_loss_terms = tuple(out[k].clone() for k in _TERM_KEYS)
             total_loss = _StepFunction.apply(self._anchor, self, total_loss) if need_bwd else total_loss.clone()
         prediction_scores = (out.get("text_logits"), out.get("ent_logits"))
         nsp_logits = out["nsp_logits"].clone()
@@ -474,6 +474,7 @@ class STonKGsForPreTraining(nn.Module):
                                   t["masked_lm_labels"], t["ent_masked_lm_labels"], t["next_sentence_labels"],
                                   self.training, False, True)
         loss = out["loss"].clone()
+        self.last_loss_terms = tuple(out[k].clone() for k in _TERM_KEYS)
         self.engine.backward(gscale, on_segment_done)
         return loss
 

@@ -48,6 +48,8 @@ class TrainingArguments:
     # clip + AdamW + W^T refresh (and the tail of the gradient all-reduce) on their own stream, beside the next step's
     # frozen-backbone forward; parameters read through the model's accessors or after torch.cuda.synchronize() are final
     optimizer_overlap: bool = True
+    # run the gradient collectives even when the process group has a single rank (hardware rehearsal of the N > 1 path)
+    ddp_force_collectives: bool = False
 
 
 def linear_schedule_lr(base_lr: float, step: int, max_steps: int, warmup: int = 0) -> float:
@@ -117,13 +119,17 @@ class GradSynchronizer:
     (7 links/GPU), so few large buckets (default 64 MB) beat DDP's 25 MB default. Averaging is folded into the
     optimizer kernel's grad_scale (sum here, 1/world there)."""
 
-    def __init__(self, grad: torch.Tensor, segments: Dict[str, int], bucket_mb: float = 64.0, group=None):
+    def __init__(self, grad: torch.Tensor, segments: Dict[str, int], bucket_mb: float = 64.0, group=None,
+                 force: bool = False):
+        """`force`: issue the collectives even in a one-rank group (a sum over one rank: the values do not change) - lets
+        a one-GPU box execute the RCCL path, its stream ordering and the kernel routing that goes with it."""
         import torch.distributed as dist
 
         self.dist = dist
         self.grad = grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.segment_end = dict(segments)  # notification name -> end offset in the flat buffer
         ends = sorted(set(segments.values()))
         self.buckets = plan_buckets(ends, int(bucket_mb * (1 << 20) / 4))
@@ -131,7 +137,7 @@ class GradSynchronizer:
         self._works = []
 
     def on_segment_done(self, name: str) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         end = self.segment_end.get(name)
         if end is None:
@@ -144,7 +150,7 @@ class GradSynchronizer:
 
     def finish(self) -> float:
         """Flush remaining buckets, wait for all of them; returns the factor that turns the sum into the mean."""
-        if self.world > 1:
+        if self.active:
             while self._next < len(self.buckets):
                 lo, hi = self.buckets[self._next]
                 self._works.append(self.dist.all_reduce(self.grad[lo:hi], op=self.dist.ReduceOp.SUM,
@@ -188,8 +194,9 @@ class Trainer:
                                     self.args.weight_decay, self.args.max_grad_norm)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.sync = GradSynchronizer(model._store.grad, segment_ends_for(model), self.args.ddp_bucket_mb)
-        model.engine.comm_overlap = self.world > 1   # (see Engine.comm_overlap)
+        self.sync = GradSynchronizer(model._store.grad, segment_ends_for(model), self.args.ddp_bucket_mb,
+                                     force=self.args.ddp_force_collectives)
+        model.engine.comm_overlap = self.sync.active   # (see Engine.comm_overlap)
         self.global_step = 0
         self._micro = 0
         self.log_history: List[dict] = []

@@ -1,0 +1,124 @@
+"""Row (e) on hardware: the data-parallel step with real collectives.
+
+* one-rank RCCL group with the collectives forced on: the nccl backend, the all-reduce issued under the weight-gradient
+  stream, the optimizer stream waiting for it and the kernel routing that goes with communication all execute on a one-GPU
+  box; a sum over one rank leaves the gradients as they are, so the result must equal the plain single-process step;
+* two ranks sharing GPU 0 over gloo (`tools/dp_check.py`): replicas bitwise identical, equal to a single process that
+  accumulates the two ranks' batches;
+* two ranks over RCCL, one per GPU - the production path (`bench.py --gpus 2` runs it too): skipped on a one-GPU box.
+Reference behaviour: DDP through HF Trainer, ref:src/stonkgs/models/stonkgs_pretraining.py:215-223."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_group(cmd, env=None, timeout=300):
+    """Run a launcher in its own process group; on a timeout the WHOLE group (ranks included) is killed, so that no rank
+    is left behind on the GPU."""
+    import signal
+
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    e.update(env or {})
+    proc = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        out, err = proc.communicate()
+        return subprocess.CompletedProcess(cmd, -9, out, "TIMEOUT\n" + err)
+    return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
+
+
+def _torchrun(n, script, *args, env=None, timeout=300):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, script), *args]
+    return _run_group(cmd, env, timeout)
+
+
+def test_rccl_path_executes_in_a_one_rank_group(hip):
+    import torch.distributed as dist
+
+    from stonkgs_amd.config import STonKGsConfig
+    from stonkgs_amd.data import synthetic_batch
+    from stonkgs_amd.stonkgs_model import STonKGsForPreTraining
+    from stonkgs_amd.stonkgs_pretraining import Trainer, TrainingArguments
+
+    cfg = STonKGsConfig(vocab_size=2048, kg_vocab_size=640, num_hidden_layers=2, hidden_dropout_prob=0.0,
+                        attention_probs_dropout_prob=0.0)
+    table = torch.randn(640, cfg.hidden_size, generator=torch.Generator().manual_seed(5), dtype=torch.float64) * 0.3
+    B = 32   # T = 16 384 tokens: the launches take the kernels the full-size step takes
+    batches = [synthetic_batch(B, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=100 + i) for i in range(2)]
+
+    init = STonKGsForPreTraining(cfg, kg_embeddings=table, seed=0)._store.data.detach().clone()
+
+    def run(force):
+        model = STonKGsForPreTraining(cfg, kg_embeddings=table, seed=0)
+        tr = Trainer(model, TrainingArguments(learning_rate=1e-3, max_steps=10, per_device_train_batch_size=B,
+                                              ddp_bucket_mb=8, ddp_force_collectives=force))
+        model.engine.comm_overlap = True        # same kernel routing in both arms
+        losses = [float(tr.training_step(model, b)) for b in batches]
+        model.engine.check_errors()
+        model.engine.wait_params()
+        torch.cuda.synchronize()
+        return losses, model._store.data.detach().clone(), tr
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        l1, p1, tr1 = run(True)
+        assert tr1.sync.active and len(tr1.sync.buckets) >= 3 and dist.get_backend() == "nccl"
+        l0, p0, tr0 = run(False)
+        assert not tr0.sync.active
+    finally:
+        dist.destroy_process_group()
+    assert l1 == pytest.approx(l0, rel=1e-5)
+    # fp32 atomics reorder addends from run to run, and Adam turns last-bit differences of near-zero gradients into +-lr
+    # steps: compare the two-step displacement of the parameters, and bound the largest difference by two lr-sized steps
+    d = (p1 - p0).abs()
+    moved1, moved0 = p1 - init, p0 - init
+    cos = torch.nn.functional.cosine_similarity(moved1.flatten(), moved0.flatten(), dim=0).item()
+    assert float(d.max()) <= 2.1e-3 and cos > 0.999, (float(d.max()), cos)
+
+
+def test_two_ranks_on_one_gpu_over_gloo(hip):
+    r = _torchrun(2, "tools/dp_check.py", env={"STONK_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0 and "DP2 OK (gloo)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_two_ranks_over_rccl(hip):
+    r = _torchrun(2, "tools/dp_check.py")
+    assert r.returncode == 0 and "DP2 OK (nccl)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_bench_gpus_2_is_a_two_rank_rccl_job(hip):
+    """`python bench.py --gpus 2` (no launcher) starts two ranks itself and reports them."""
+    r = _run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                    "--no-roofline"], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 128 and line["config"]["parallelism"] == "dp2"
+
+
+def test_bench_refuses_more_ranks_than_gpus(hip):
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "visible" in r.stderr

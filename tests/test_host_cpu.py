@@ -210,3 +210,42 @@ def test_bench_contract_constants():
     assert line["metric"] == metric and line["config"]["workload"] and line["vs_baseline"] is None
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
     assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+
+
+def test_bench_spawns_ranks_and_refuses_a_mismatched_launcher(monkeypatch):
+    """`bench.py --gpus N` outside a launcher starts N ranks through torch.distributed.run as a child process (the
+    parent never initialises a GPU); inside a launcher whose WORLD_SIZE differs from --gpus it refuses to report."""
+    import importlib
+    import subprocess
+    import sys
+
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    calls = {}
+
+    def fake_run(cmd, env=None, **kw):
+        calls["cmd"], calls["env"] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7   # the child's exit code is relayed
+    cmd = calls["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:   # fewer GPUs than ranks: loud failure, no 1-rank run under an N-GPU label
+        bench.main()
+    assert e.value.code == 2
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 2

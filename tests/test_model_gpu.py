@@ -75,8 +75,7 @@ def test_forward_matches_reference_golden(g2):
 def test_backward_matches_reference_golden(g2):
     cfg, sd, tsv_rows, batch, gold, meta, model = g2
     model.train()
-    model.zero_grad()
-    model._store.grad.zero_()
+    model.zero_grad()      # zeroes the flat gradient buffer the engine accumulates into
     loss = model(**batch)[0]
     assert abs(float(loss) - float(gold["loss"])) < 2e-2
     loss.backward()
@@ -153,7 +152,7 @@ def test_against_oracle_on_fresh_batch_and_masks(g2):
     res = orc.train_step(sd2, cfg, table, b, orc.AdamState(), max_grad_norm=0.0)
     model.load_state_dict(sd, strict=False)
     model.train()
-    model._store.grad.zero_()
+    model.zero_grad()
     loss = model.forward_backward(b)
     assert abs(float(loss) - float(res["loss"])) < 2e-2
     gv = model.named_grad_views()

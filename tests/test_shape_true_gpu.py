@@ -1,0 +1,180 @@
+"""Shape-true parity of the whole hot path (VERDICT round 1, items 2 and 3 of "What's missing"):
+
+  (a) real depth / width / heads: the HIP model at 12L / 768h / 12 heads / S = 512 / V = 28 996 (K = 4 096) against golden
+      vectors made by the REFERENCE's own forward and backward (tests/golden/g3_shapetrue, oracle/make_golden.py shape);
+  (b) real vocabulary widths and the full-size step's kernels: 2L / 768h / S = 512 / V = 28 996 / K = 175 094 at B = 32
+      (T = 16 384 tokens: four-wave weight gradients, the 256-tile decoder dgrad, fp16 logits of 175 104 columns, the
+      5.7 GB-extent entity-decoder wgrad operand class) against the oracle: loss terms, global gradient norm and EVERY
+      gradient tensor, `entity_decoder.weight` included;
+  (c) BASELINE config 1: the 3-row example batch at 12L / 768h, K = 1 000, against the oracle (loss, logits, pooled).
+Reference: ref:src/stonkgs/models/stonkgs_model.py:149-258 (forward), :62-73 (heads), :223-245 (losses).
+bf16 MFMA compute against fp32: tolerances are stated at each check, a small multiple of what was measured."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stonkgs_oracle as orc
+from tests.golden_util import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    if b.norm() < 1e-5:
+        return (a - b).norm().item() / 1e-2
+    return ((a - b).norm() / b.norm()).item()
+
+
+def _build(cfg, sd, tsv_rows):
+    from stonkgs_amd.config import STonKGsConfig
+    from stonkgs_amd.stonkgs_model import STonKGsForPreTraining
+
+    c = STonKGsConfig(**{k: getattr(cfg, k) for k in ("vocab_size", "kg_vocab_size", "hidden_size", "num_hidden_layers",
+                                                      "num_attention_heads", "intermediate_size",
+                                                      "max_position_embeddings", "type_vocab_size", "layer_norm_eps")},
+                      hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    model = STonKGsForPreTraining(c, kg_embeddings=tsv_rows)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all("decoder" in k for k in missing), (missing, unexpected)
+    return model
+
+
+def _slice_of(spec):
+    return tuple(slice(a, b, c) for a, b, c in spec)
+
+
+def test_real_depth_matches_reference_golden(hip):
+    cfg, sd, tsv_rows, batch, gold, meta = load_case("g3_shapetrue")
+    assert (cfg.num_hidden_layers, cfg.hidden_size, cfg.num_attention_heads, cfg.max_position_embeddings) == (12, 768, 12, 512)
+    model = _build(cfg, sd, tsv_rows)
+    del sd
+    model.train()           # p = 0: train mode only selects the label-sparse training path + backward
+    model.zero_grad()
+    model.materialize_logits = True
+    out = model(**batch, return_dict=True)
+    out.loss.backward()
+    model.engine.check_errors()
+    dl = abs(float(out.loss) - float(gold["loss"]))
+    terms = [float(t) for t in model.last_loss_terms]
+    dterms = [abs(t - float(gold[k])) for t, k in zip(terms, ("masked_lm_loss", "ent_masked_lm_loss", "next_sentence_loss"))]
+    print(f"real depth: |dloss| {dl:.2e} terms {['%.2e' % d for d in dterms]}")
+    assert dl < 1e-2 and max(dterms) < 1e-2          # loss 19.6; measured 1-3e-3
+    for sid in (100, 102, 103):
+        assert _rel(model.kg_backbone[sid], gold[f"special_{sid}"]) < 2e-2
+    assert _rel(out.pooler_output, gold["pooler_output"]) < 2e-2
+    assert _rel(out.seq_relationship_logits, gold["nsp_logits"]) < 3e-2
+    assert _rel(out.hidden_states[:, ::37, ::11], gold["hidden_states_s"]) < 2e-2
+    tl, el = out.prediction_logits
+    assert tl.shape == (2, 256, cfg.vocab_size) and el.shape == (2, 256, cfg.kg_vocab_size)
+    assert _rel(tl[batch["masked_lm_labels"].cuda() != -100][:, ::97], gold["text_logits_lab_s"]) < 3e-2
+    assert _rel(el[batch["ent_masked_lm_labels"].cuda() != -100][:, ::29], gold["ent_logits_lab_s"]) < 3e-2
+    gv = model.named_grad_views()
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in gv.values()))
+    assert abs(float(total) - float(gold["grad_norm"])) < 2e-2 * float(gold["grad_norm"])
+    worst = ("", 0.0)
+    for name, ref_norm in zip(meta["grad_names"], gold["grad_norms"]):      # EVERY gradient tensor, by its norm
+        got = float(gv[name].double().norm())
+        # (key.bias: analytically zero - softmax ignores a per-query constant - compared on an absolute scale)
+        err = abs(got - ref_norm) / (ref_norm if ref_norm >= 1e-5 else 1e-2)
+        worst = max(worst, (name, err), key=lambda t: t[1])
+        assert err < 5e-2, (name, got, ref_norm)
+    print("worst per-tensor gradient-norm error:", worst)
+    for k in meta["grad_keys"]:
+        e = _rel(gv[k][_slice_of(meta["grad_slices"][k])], gold["grad_s::" + k])
+        assert e < 6e-2, (k, e)
+
+
+def _chunked_oracle_step(sd, cfg, table, batch, chunk):
+    """Oracle loss terms and gradients of a large batch from `chunk`-row pieces: every row carries the same number of
+    labels per head (int(half * 0.15), padding included - ref:indra_for_pretraining.py:33-77), so the batch means are the
+    means of the chunk means and the gradients average."""
+    B = batch["input_ids"].shape[0]
+    assert B % chunk == 0
+    n = B // chunk
+    tot, grads = {}, None
+    for i in range(n):
+        piece = {k: v[i * chunk:(i + 1) * chunk] for k, v in batch.items()}
+        r = orc.train_step(dict(sd), cfg, table, piece, orc.AdamState(), max_grad_norm=0.0, base_lr=0.0)
+        for k in ("loss", "masked_lm_loss", "ent_masked_lm_loss", "next_sentence_loss"):
+            tot[k] = tot.get(k, 0.0) + float(r[k]) / n
+        if grads is None:
+            grads = {k: g / n for k, g in r["grads"].items()}
+        else:
+            for k, g in r["grads"].items():
+                grads[k] += g / n
+    return tot, grads
+
+
+def test_full_vocabulary_step_kernels_against_oracle(hip):
+    from stonkgs_amd.data import synthetic_batch
+
+    cfg = orc.OracleConfig(num_hidden_layers=2)          # H 768, 12 heads, S 512, V 28 996, K 175 094
+    sd = orc.init_state_dict(cfg, seed=21)
+    g = torch.Generator().manual_seed(22)
+    tsv_rows = torch.randn(cfg.kg_vocab_size, cfg.hidden_size, generator=g, dtype=torch.float64) * 0.3
+    B = 32
+    batch = synthetic_batch(B, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=23)
+    lab = (batch["masked_lm_labels"] != -100).sum(1), (batch["ent_masked_lm_labels"] != -100).sum(1)
+    assert int(lab[0].min()) == int(lab[0].max()) == 38 and int(lab[1].min()) == int(lab[1].max()) == 38
+    model = _build(cfg, sd, tsv_rows)
+    eng = model.engine
+    assert eng.f16_logits and eng.overlap_wgrad            # the bench's configuration
+    assert eng._split_k(3 * 768, 768, B * 512, True) < 0   # four-wave weight-gradient kernel on the second stream
+    model.train()
+    model.zero_grad()
+    loss = model.forward_backward(batch)
+    eng.check_errors()
+    torch.cuda.synchronize()
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    with torch.no_grad():
+        table = orc.build_kg_table(tsv_rows, orc.special_vectors(sd, cfg))
+    ref, rgrads = _chunked_oracle_step(sd, cfg, table, batch, 4)
+    terms = [float(t) for t in model.last_loss_terms]
+    d = [abs(float(loss) - ref["loss"])] + [abs(t - ref[k]) for t, k in
+                                            zip(terms, ("masked_lm_loss", "ent_masked_lm_loss", "next_sentence_loss"))]
+    print("full vocabulary: |dloss|, |dterms| =", ["%.2e" % x for x in d])
+    assert max(d) < 1e-2                                   # total loss ~23; measured ~2e-3 (fp16 logits included)
+    gv = model.named_grad_views()
+    assert set(gv) == set(rgrads)
+    tot = torch.sqrt(sum((v.double() ** 2).sum() for v in gv.values()))
+    rtot = torch.sqrt(sum((v.double() ** 2).sum() for v in rgrads.values()))
+    assert abs(float(tot) - float(rtot)) < 2e-2 * float(rtot)
+    errs = {k: _rel(gv[k], rgrads[k]) for k in rgrads}     # EVERY gradient tensor
+    worst = max(errs.items(), key=lambda t: t[1])
+    print("worst gradient tensor:", worst, "| entity decoder:", errs["cls.predictions.entity_decoder.weight"],
+          "| text decoder:", errs["cls.predictions.text_decoder.weight"])
+    assert worst[1] < 6e-2, worst
+    assert errs["cls.predictions.entity_decoder.weight"] < 3e-2 and errs["cls.predictions.text_decoder.weight"] < 3e-2
+    # the padded decoder rows (28 996 -> 29 056, 175 094 -> 175 104) never receive a gradient
+    st = model._store
+    assert float(st.grad_view("cls.predictions.entity_decoder.weight", padded=True)[cfg.kg_vocab_size:].abs().max()) == 0.0
+    assert float(st.grad_view("cls.predictions.text_decoder.weight", padded=True)[cfg.vocab_size:].abs().max()) == 0.0
+
+
+def test_config1_example_batch_at_12_layers(hip):
+    """BASELINE.json configs[0]: the 3-row example_df-shaped batch (11 / 13 / 12 real text tokens, 241+ padded positions
+    that the frozen backbone still attends - quirk Q5) through the 12L / 768h model, K = 1 000."""
+    from stonkgs_amd.data import example_batch
+
+    cfg = orc.OracleConfig(kg_vocab_size=1000)
+    sd = orc.init_state_dict(cfg, seed=0)
+    g = torch.Generator().manual_seed(1)
+    tsv_rows = torch.randn(cfg.kg_vocab_size, cfg.hidden_size, generator=g, dtype=torch.float64) * 0.3
+    batch = example_batch(cfg.vocab_size, cfg.kg_vocab_size, 512, seed=0)
+    assert batch["input_ids"].shape == (3, 512) and batch["attention_mask"][:, :256].sum(1).tolist() == [13, 15, 14]
+    model = _build(cfg, sd, tsv_rows)
+    model.eval()
+    with torch.no_grad():
+        out = model(**batch, return_dict=True)
+        model.engine.check_errors()
+        table = orc.build_kg_table(tsv_rows, orc.special_vectors(sd, cfg))
+        ref = orc.forward(sd, cfg, table, **batch)
+    d = abs(float(out.loss) - float(ref["loss"]))
+    print(f"config 1: HIP loss {float(out.loss):.4f} oracle {float(ref['loss']):.4f} |d| {d:.2e}")
+    assert d < 1e-2
+    assert _rel(out.pooler_output, ref["pooler_output"]) < 2e-2
+    assert _rel(out.hidden_states, ref["hidden_states"]) < 2e-2
+    tl, el = out.prediction_logits
+    assert _rel(tl, ref["text_logits"]) < 3e-2 and _rel(el, ref["ent_logits"]) < 3e-2
+    assert _rel(out.seq_relationship_logits, ref["nsp_logits"]) < 3e-2

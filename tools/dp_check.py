@@ -1,7 +1,10 @@
-"""Two data-parallel ranks on ONE GPU over gloo (development check of the multi-GPU step logic on a one-GPU box: bucketed
-all-reduce issued under the weight-gradient stream, optimizer waiting for it, the dynamically scheduled dgrad kernel while
-communication holds CUs). Launch:
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/dp2_gloo_gpu.py
+"""N data-parallel ranks of the training step, checked against each other and against one process:
+  * backend "nccl" (= RCCL, default when there are at least as many GPUs as ranks): one rank per GPU, the production path;
+  * backend "gloo" (STONK_DIST_BACKEND=gloo): all ranks on GPU 0 - a rehearsal of the multi-GPU step logic on a one-GPU box
+    (bucketed all-reduce issued under the weight-gradient stream, optimizer waiting for it, the dynamically scheduled
+    dgrad kernel while communication holds CUs).
+Launch (tests/test_dist_gpu.py does):
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/dp_check.py
 Checks: both ranks end with bitwise-identical parameters; they match a single-process run that accumulates the two
 ranks' batches (DDP semantics: mean over ranks of per-rank mean losses) within fp32 round-off of the atomics."""
 import os
@@ -26,9 +29,15 @@ def build(seed=0):
 
 
 def main():
-    dist.init_process_group("gloo")
+    backend = os.environ.get("STONK_DIST_BACKEND", "nccl")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
     B = 32
     cfg, model = build()
     tr = Trainer(model, TrainingArguments(learning_rate=1e-3, max_steps=10, per_device_train_batch_size=B, ddp_bucket_mb=8))
@@ -42,6 +51,7 @@ def main():
     flat = model._store.data.detach().clone()
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
+    gathered = [g.to(flat.device) for g in gathered]
     same = all(torch.equal(gathered[0], g) for g in gathered)
     if rank == 0 and not same:
         diff = (gathered[0] != gathered[1]).nonzero().flatten()
@@ -60,7 +70,7 @@ def main():
         cfg2, ref = build()
         tr2 = Trainer(ref, TrainingArguments(learning_rate=1e-3, max_steps=10, per_device_train_batch_size=B,
                                              gradient_accumulation_steps=world))
-        tr2.world, tr2.sync.world = 1, 1
+        tr2.world, tr2.sync.world, tr2.sync.active = 1, 1, False
         ref.engine.comm_overlap = False
         for step in range(2):
             for r in range(world):
@@ -70,7 +80,7 @@ def main():
         scale = (ref._store.data.abs().max().item())
         print(f"ranks identical: {same}; losses {losses}; max |dp - accumulated| = {d:.3e} (param scale {scale:.2f})", flush=True)
         assert same and d < 2e-3, (same, d)
-        print("DP2 OK", flush=True)
+        print(f"DP{world} OK ({backend})", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -96,19 +96,11 @@ int stonk_embed_grad(const void* dx, const int64_t* token_type_ids, float* dpos,
 int stonk_attention_fwd(const void* q, const void* k, const void* v, int64_t ld, const int64_t* attention_mask,
                         void* out, int64_t ldo, float* lse, int B, int NH, int S, int D, float scale, float drop_p,
                         uint32_t seed, void* stream);
-/* Backward of the above (recomputes P from lse; no atomics, bitwise reproducible). delta_ws: fp32 [B,NH,S] scratch.
- * S = 256 / 512: ONE kernel, a workgroup per (sequence, head) holding dK / dV of all keys in accumulators, S and dP
- * computed once, dS crossing LDS once for dQ. Other S: the two-kernel form below. ldo, lddo, ldd % 8 == 0. */
+/* Backward of the above (recomputes P from lse; no atomics). delta_ws: fp32 [B,NH,S] scratch. */
 int stonk_attention_bwd(const void* q, const void* k, const void* v, int64_t ld, const int64_t* attention_mask,
                         const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta_ws,
                         void* dq, void* dk, int64_t ldd, void* dv, int B, int NH, int S, int D, float scale,
                         float drop_p, uint32_t seed, void* stream);
-/* The same result from two kernels (dQ with the query on the lane, then dK / dV with the key on the lane; each recomputes
- * S and dP): any S % 128 == 0. Same arguments. */
-int stonk_attention_bwd_split(const void* q, const void* k, const void* v, int64_t ld, const int64_t* attention_mask,
-                              const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
-                              float* delta_ws, void* dq, void* dk, int64_t ldd, void* dv, int B, int NH, int S, int D,
-                              float scale, float drop_p, uint32_t seed, void* stream);
 
 /* out[c][r] = in[r][c] (bf16). Rows >= *rows_dev (nullable) read as zero; colsum (nullable, fp32) += column sums
  * of `in` (bias gradients). Feeds wgrad operands to stonk_gemm_nt_bf16. */

@@ -13,8 +13,6 @@
 //    softmax statistics are per-lane scalars and P^T feeds the next MFMA as B operand with no LDS trip;
 //  * dK/dV compute S = Q.K^T (key on the lane) so P and dS feed dV^T / dK^T the same way.
 // K^T / V^T / Q^T / dO^T operands come from row-major LDS tiles through ds_read_b64_tr_b16.
-#include <type_traits>
-
 #include "common.h"
 #include "stonk_flags.h"
 
@@ -549,316 +547,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
     }
 }
 
-// ------------------------------------------------------------------ backward in ONE kernel (S = 256 or 512)
-// The two-kernel backward above recomputes S and dP in both kernels: 7 MFMA products and two exp / dropout-hash passes per
-// score, where the algorithm needs 5 and one. Here ONE workgroup owns a whole (sequence, head): NW = S/64 waves, wave w
-// keeps dK^T and dV^T of keys 64w .. 64w+63 in 128 accumulator registers and the workgroup sweeps the queries in slices
-// of 32 rows. Per slice a wave computes S and dP with the KEY on the lane (so P and dS are the B operands of the dV^T and
-// dK^T products straight from the accumulators), and writes dS once, transposed, into an LDS image [key][query]; after the
-// slice's barrier the waves share out the slice's dQ^T = K^T . dS^T as eight 16x16 tiles over all S keys
-// (v_mfma_f32_16x16x32_bf16, both operands by ds_read_b64_tr_b16). dQ, dK and dV are complete inside the workgroup:
-// no atomics, no second pass, bitwise reproducible. delta = rowsum(dO . O) is computed while the dO slice is staged.
-// LDS (S = 512): K image 64 KiB + two dS^T images 64 KiB + two (Q, dO, -lse, delta) stages 16.5 KiB + two dQ slices 8 KiB
-// = 152.5 KiB, one workgroup per CU, two waves per SIMD; one barrier per slice.
-constexpr int FB_QB = 32;                  // query rows per slice
-constexpr int FB_DSROW = 64;               // bytes per key row of a dS^T image (32 queries)
-constexpr int FB_STAGE = 2 * 4096 + 256;   // Q slice, dO slice, -lse*log2(e) [32], (1-p)*delta [32]
-template <int NW, int KB>
-struct FusedLds {
-  static constexpr int S = NW * KB * 32;
-  static constexpr int KIMG = 0;
-  static constexpr int DSIMG = S * ROWB;
-  static constexpr int STG = DSIMG + 2 * S * FB_DSROW;
-  static constexpr int DQB = STG + 2 * FB_STAGE;
-  static constexpr int BYTES = DQB + 2 * 4096;
-};
-// byte offset of dS^T[key][q] (q in 0..31): the two 32-byte halves of a row swap every 8 keys, so that the two 4-key blocks
-// a 32-lane half of a transposed read takes (8 keys apart) fall into different banks
-__device__ __forceinline__ int ds_off(int key, int q) {
-  return key * FB_DSROW + ((((q >> 4) ^ (key >> 3)) & 1) << 5) + ((q & 15) << 1);
-}
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
-// Operands of v_mfma_f32_16x16x32_bf16 read transposed: lane l gets, for its row/column i = l & 15 of the 16-wide side,
-// the 8 keys key0 + 8 * (l >> 4) + j (A and B use the same key order, so any order is a valid contraction).
-__device__ __forceinline__ bf16x8 tr16_kimg(const char* kimg, int key0, int d0, int lane) {
-  const int i = lane & 15, g4 = lane >> 4;
-  const int key = key0 + 8 * g4 + (i >> 2), col = d0 + 4 * (i & 3);
-  const char* t = kimg + (key >> 6) * TILEB;
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(t + tile_off(key & 63, col)));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(t + tile_off((key & 63) + 4, col)));
-  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-__device__ __forceinline__ bf16x8 tr16_dsimg(const char* dsimg, int key0, int q0, int lane) {
-  const int i = lane & 15, g4 = lane >> 4;
-  const int key = key0 + 8 * g4 + (i >> 2), q = q0 + 4 * (i & 3);
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(dsimg + ds_off(key, q)));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(dsimg + ds_off(key + 4, q)));
-  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
-// c += a . b with the accumulator PINNED to the AGPR half of the register file: the kernel runs one wave per SIMD with the
-// whole 512-entry file, 256 of it dK^T / dV^T. Left to itself the allocator put the S / dP tiles (which VALU code reads) in
-// AGPRs instead and copied them back and forth (1100 v_accvgpr moves per slice). The compiler does not see inside an asm
-// statement: a VALU-produced operand (the packed P / dS) needs a wait state before an MFMA reads it - the s_nop; the
-// accumulator chain itself is MFMA -> MFMA on exactly overlapping registers, which the hardware interlocks.
-__device__ __forceinline__ void mfma32_acc(f32x16& c, bf16x8 a, bf16x8 b) {
-  asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-
-// ... and the S / dP tiles, which VALU code reads, pinned to arch VGPRs; `mfma_results_ready` makes the consumers depend on
-// the wait an XDL result needs before a VALU read (up to 19 wait states), which the compiler cannot add for an asm producer.
-__device__ __forceinline__ void mfma32_v(f32x16& c, bf16x8 a, bf16x8 b) {
-  asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void mfma_results_ready(f32x16& x, f32x16& y) {
-  asm("s_nop 15\n\ts_nop 3" : "+v"(x), "+v"(y));
-}
-
-template <int NW, int KB, bool HAS_MASK, bool DROPOUT>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(const AttnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  using L = FusedLds<NW, KB>;
-  constexpr int S = L::S, NT = NW * 64, NIT = S / FB_QB, CH = 512 / NT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, hh = lane >> 5;
-  const int bh = blockIdx.x;
-  const int b = bh / p.NH, h = bh - b * p.NH;
-  const long tok0 = (long)b * S;
-  const long statbase = (long)bh * S;
-  const float sc2 = p.scale * LOG2E;
-  const int k0 = wave * (32 * KB);
-
-  // K image of the whole sequence (row reads for S, transposed reads for dQ)
-#pragma unroll 2
-  for (int id = tid; id < S * 8; id += NT) {
-    const int row = id >> 3, c = id & 7;
-    const bf16x8 v = *(const bf16x8*)(p.k + (tok0 + row) * p.ld + h * HD + c * 8);
-    *(bf16x8*)(lds + L::KIMG + (row >> 6) * TILEB + tile_off(row & 63, c * 8)) = v;
-  }
-  asm volatile("" ::: "memory");   // (keeps the image copy's staging registers from overlapping the fragment loads below)
-  bf16x8 vf[KB][4];
-  float mb[KB];
-  uint32_t ck[KB];
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
-    mb[kb] = 0.f;
-    const bf16* vrow = p.v + (tok0 + k0 + 32 * kb + r) * p.ld + h * HD;
-#pragma unroll
-    for (int st = 0; st < 4; ++st) vf[kb][st] = *(const bf16x8*)(vrow + 16 * st + 8 * hh);
-    if (HAS_MASK) mb[kb] = p.mask[tok0 + k0 + 32 * kb + r] != 0 ? 0.f : NEG_MASK;
-    ck[kb] = stonk_colkey((uint32_t)(k0 + 32 * kb + r));
-  }
-  f32x16 dk[KB][2], dv[KB][2];
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dk[kb][0][i] = dk[kb][1][i] = dv[kb][0][i] = dv[kb][1][i] = 0.f;
-  const uint32_t rk_lane = stonk_rowkey((uint32_t)(statbase + 4 * hh), p.seed);
-  const float inv_ds = DROPOUT ? 1.f / p.drop_scale : 1.f;
-  const float fs = DROPOUT ? p.scale * p.drop_scale : p.scale;
-
-  bf16x8 stg[CH];
-  float dpart[CH];
-  float sreg = 0.f;
-  // per-lane element offsets of this thread's chunks inside a slice (32-bit; the slice bases below are wave-uniform)
-  int lq[CH], ld_o[CH], lo_o[CH];
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int id = tid + c * NT, row = (id & 255) >> 3, cc = id & 7;
-    lq[c] = row * (int)p.ld + cc * 8;
-    ld_o[c] = row * (int)p.lddo + cc * 8;
-    lo_o[c] = row * (int)p.ldo + cc * 8;
-  }
-  auto load_slice = [&](int it) {
-    const bf16* qb = p.q + (tok0 + it * FB_QB) * p.ld + h * HD;
-    const bf16* db = p.dout + (tok0 + it * FB_QB) * p.lddo + h * HD;
-    const bf16* ob = p.out + (tok0 + it * FB_QB) * p.ldo + h * HD;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int id = tid + c * NT;
-      if (id < 256) {
-        stg[c] = *(const bf16x8*)(qb + lq[c]);
-      } else {
-        stg[c] = *(const bf16x8*)(db + ld_o[c]);
-        const bf16x8 of = *(const bf16x8*)(ob + lo_o[c]);
-        float d = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) d += (float)of[j] * (float)stg[c][j];
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        d += __shfl_xor(d, 4, 64);
-        dpart[c] = d * inv_ds;   // (1-p) * delta
-      }
-    }
-    if (tid < FB_QB) sreg = -(p.lse + statbase + it * FB_QB)[tid] * LOG2E;
-  };
-  auto store_slice = [&](int stage) {
-    char* base = lds + L::STG + stage * FB_STAGE;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int id = tid + c * NT, row = (id & 255) >> 3, cc = id & 7;
-      if (id < 256) {
-        *(bf16x8*)(base + tile_off(row, cc * 8)) = stg[c];
-      } else {
-        *(bf16x8*)(base + 4096 + tile_off(row, cc * 8)) = stg[c];
-        if (cc == 0) ((float*)(base + 8192))[FB_QB + row] = dpart[c];
-      }
-    }
-    if (tid < FB_QB) ((float*)(base + 8192))[tid] = sreg;
-  };
-  auto store_dq = [&](int it) {
-    const char* dqb = lds + L::DQB + (it & 1) * 4096;
-    bf16* gb = p.dq + (tok0 + it * FB_QB) * p.ldd + h * HD;
-    for (int id = tid; id < 256; id += NT) {
-      const int row = id >> 3, cc = id & 7;
-      *(bf16x8*)(gb + row * (int)p.ldd + cc * 8) = *(const bf16x8*)(dqb + row * 128 + cc * 16);
-    }
-  };
-  load_slice(0);
-  store_slice(0);
-  __syncthreads();
-
-  const int kt_off = L::KIMG + (k0 >> 6) * TILEB + (k0 & 63) * ROWB;   // this wave's keys (k0 % 32 == 0: whole swizzle periods)
-  for (int it = 0; it < NIT; ++it) {
-    const int stage = it & 1;
-    const char* Qs = lds + L::STG + stage * FB_STAGE;
-    const char* Ds = Qs + 4096;
-    const float* Ls = (const float*)(Qs + 8192);
-    const float* Dl = Ls + FB_QB;
-    char* dsimg = lds + L::DSIMG + stage * (S * FB_DSROW);
-    const char* Kt = lds + kt_off;
-    if (it + 1 < NIT) load_slice(it + 1);
-    const uint32_t rkt = rk_lane + (uint32_t)(it * FB_QB) * STONK_G_ROW;
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      f32x16 s, dp;
-      float mbk = mb[kb];
-      asm volatile("" : "+v"(mbk));   // (opaque: a 16-register splat of the bias hoisted out of the loop would be spilled)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        s[i] = mbk;
-        dp[i] = 0.f;
-      }
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        s = mfma32(row_frag(Qs, 0, st, r, hh), row_frag(Kt, 32 * kb, st, r, hh), s);   // S[q][k] (+ key bias)
-        dp = mfma32(row_frag(Ds, 0, st, r, hh), vf[kb][st], dp);                       // dP[q][k]
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 nls = *(const f32x4*)(Ls + 8 * g + 4 * hh);
-        const f32x4 dl = *(const f32x4*)(Dl + 8 * g + 4 * hh);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int i = 4 * g + j;
-          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sc2, nls[j]));
-          float pd = pr, dpv = dp[i];
-          if (DROPOUT) {
-            const uint32_t rj = (uint32_t)(8 * g + j) * STONK_G_ROW;
-            const bool keep = stonk_keep_key(rkt + rj, ck[kb], p.drop_thr32);
-            pd = keep ? pr : 0.f;
-            dpv = keep ? dpv : 0.f;
-          }
-          s[i] = pd;                    // dropped P (feeds dV), up to the folded 1/(1-p)
-          dp[i] = pr * (dpv - dl[j]);   // dS (feeds dK and dQ), up to the folded 1/(1-p)
-        }
-      }
-      // dS^T slice: lane = key, registers 4g..4g+3 = queries 8g + 4hh .. +3
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const bf16x4 w = {(bf16)dp[4 * g], (bf16)dp[4 * g + 1], (bf16)dp[4 * g + 2], (bf16)dp[4 * g + 3]};
-        *(bf16x4*)(dsimg + ds_off(k0 + 32 * kb + r, 8 * g + 4 * hh)) = w;
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 pf, dsf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          pf[j] = (bf16)s[8 * ks + j];
-          dsf[j] = (bf16)dp[8 * ks + j];
-        }
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dv[kb][dt] = mfma32(tr_frag(Ds, 16 * ks, dt * 32, lane), pf, dv[kb][dt]);    // dV^T += dO^T . P
-          dk[kb][dt] = mfma32(tr_frag(Qs, 16 * ks, dt * 32, lane), dsf, dk[kb][dt]);   // dK^T += Q^T . dS
-        }
-      }
-    }
-    if (it + 1 < NIT) store_slice(stage ^ 1);
-    __syncthreads();
-    if (it > 0) store_dq(it - 1);
-    // dQ^T tile (16 d x 16 q) over all keys: per 32-key step the operand addresses advance by a constant (the swizzles of
-    // both images have a period of 16 keys), so each operand is one lane offset plus a running byte offset
-    for (int t = wave; t < 8; t += NW) {
-      const int qh = t & 1, dc = t >> 1;
-      const int i16 = lane & 15, g4 = lane >> 4;
-      const int rr = 8 * g4 + (i16 >> 2);
-      const char* ka = lds + L::KIMG + tile_off(rr, 16 * dc + 4 * (i16 & 3));
-      const char* kb4 = lds + L::KIMG + tile_off(rr + 4, 16 * dc + 4 * (i16 & 3));
-      const char* da = dsimg + ds_off(rr, 16 * qh + 4 * (i16 & 3));
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-      for (int ks = 0; ks < S / 32; ks += 2) {
-        bf16x8 a[2], bq[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int ko = (ks + u) * (32 * ROWB), so = (ks + u) * (32 * FB_DSROW);
-          const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(ka + ko));
-          const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(kb4 + ko));
-          const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(da + so));
-          const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(da + so + 4 * FB_DSROW));
-          a[u] = (bf16x8){alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
-          bq[u] = (bf16x8){blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-        }
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bq[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bq[1], acc1, 0, 0, 0);
-      }
-      const bf16x4 w = {(bf16)((acc0[0] + acc1[0]) * fs), (bf16)((acc0[1] + acc1[1]) * fs), (bf16)((acc0[2] + acc1[2]) * fs),
-                        (bf16)((acc0[3] + acc1[3]) * fs)};
-      *(bf16x4*)(lds + L::DQB + stage * 4096 + (16 * qh + i16) * 128 + (16 * dc + 4 * g4) * 2) = w;
-    }
-  }
-  __syncthreads();
-  store_dq(NIT - 1);
-  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // (the last MFMAs above are asm: their results are read by VALU code below)
-  const float fk = fs;
-  const float fv = DROPOUT ? p.drop_scale : 1.f;
-  // one accumulator tile at a time (the scheduler would otherwise read all 256 accumulator registers back at once)
-  auto store_tile_t = [&](const f32x16& acc, bf16* row, float f) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const bf16x4 a = {(bf16)(acc[4 * g] * f), (bf16)(acc[4 * g + 1] * f), (bf16)(acc[4 * g + 2] * f), (bf16)(acc[4 * g + 3] * f)};
-      *(bf16x4*)(row + 8 * g + 4 * hh) = a;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
-    bf16* krow = p.dk + (tok0 + k0 + 32 * kb + r) * p.ldd + h * HD;
-    bf16* vrow = p.dv + (tok0 + k0 + 32 * kb + r) * p.ldd + h * HD;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      store_tile_t(dk[kb][dt], krow + dt * 32, fk);
-      store_tile_t(dv[kb][dt], vrow + dt * 32, fv);
-    }
-  }
-}
-
-template <int NW, int KB, bool HM, bool DR>
-int launch_bwd_fused(const AttnArgs& a, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<NW, KB, HM, DR>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, FusedLds<NW, KB>::BYTES);
-    attr_done = true;
-  }
-  constexpr int lds_bytes = FusedLds<NW, KB>::BYTES;
-  hipLaunchKernelGGL((attn_bwd_fused_kernel<NW, KB, HM, DR>), dim3(a.B * a.NH), dim3(NW * 64), lds_bytes, st, a);
-  return stonk_launch_status();
-}
-
 int check_common(const void* q, const void* k, const void* v, int64_t ld, int B, int NH, int S, int D) {
   STONK_CHECK_ARG(q && k && v, STONK_EINVAL);
   STONK_CHECK_ARG(D == HD, STONK_ESHAPE);
@@ -894,15 +582,15 @@ extern "C" int stonk_attention_fwd(const void* q, const void* k, const void* v, 
   return stonk_launch_status();
 }
 
-static int attention_bwd_impl(bool allow_fused, const void* q, const void* k, const void* v, int64_t ld,
-                              const int64_t* attention_mask, const void* out, int64_t ldo, const void* dout, int64_t lddo,
-                              const float* lse, float* delta_ws, void* dq, void* dk, int64_t ldd, void* dv, int B, int NH,
-                              int S, int D, float scale, float drop_p, uint32_t seed, void* stream) {
+extern "C" int stonk_attention_bwd(const void* q, const void* k, const void* v, int64_t ld,
+                                   const int64_t* attention_mask, const void* out, int64_t ldo, const void* dout,
+                                   int64_t lddo, const float* lse, float* delta_ws, void* dq, void* dk, int64_t ldd,
+                                   void* dv, int B, int NH, int S, int D, float scale, float drop_p, uint32_t seed,
+                                   void* stream) {
   int rc = check_common(q, k, v, ld, B, NH, S, D);
   if (rc) return rc;
   STONK_CHECK_ARG(out && dout && lse && delta_ws && dq && dk && dv, STONK_EINVAL);
-  STONK_CHECK_ARG(ldo % 8 == 0 && lddo % 8 == 0 && ldd % 8 == 0, STONK_EALIGN);
-  STONK_CHECK_ARG((uintptr_t)dq % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)dout % 16 == 0, STONK_EALIGN);
+  STONK_CHECK_ARG(ldo % 8 == 0 && lddo % 8 == 0 && ldd % 4 == 0, STONK_EALIGN);
   STONK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, STONK_EINVAL);
   if (B == 0) return STONK_OK;
   AttnArgs a = {};
@@ -913,20 +601,8 @@ static int attention_bwd_impl(bool allow_fused, const void* q, const void* k, co
   a.B = B; a.NH = NH; a.S = S; a.scale = scale;
   a.drop_thr32 = stonk_drop_thr32(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = stonk_seed_mix(seed);
   hipStream_t st = (hipStream_t)stream;
-  const bool hm = attention_mask != nullptr, dr = drop_p > 0.f;
-  if (allow_fused && (S == 512 || S == 256)) {
-#define LAUNCH_FUSED(NW, KB)                                              \
-  do {                                                                    \
-    if (hm && dr) return launch_bwd_fused<NW, KB, true, true>(a, st);     \
-    if (hm) return launch_bwd_fused<NW, KB, true, false>(a, st);          \
-    if (dr) return launch_bwd_fused<NW, KB, false, true>(a, st);          \
-    return launch_bwd_fused<NW, KB, false, false>(a, st);                 \
-  } while (0)
-    if (S == 512) LAUNCH_FUSED(8, 2);
-    LAUNCH_FUSED(4, 2);
-#undef LAUNCH_FUSED
-  }
   const dim3 grid(S / 128, NH, B), block(256);
+  const bool hm = attention_mask != nullptr, dr = drop_p > 0.f;
 #define LAUNCH_BWD(HM, DR)                                                                  \
   do {                                                                                      \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HM, DR>), grid, block, 0, st, a);                \
@@ -938,22 +614,4 @@ static int attention_bwd_impl(bool allow_fused, const void* q, const void* k, co
   else LAUNCH_BWD(false, false);
 #undef LAUNCH_BWD
   return stonk_launch_status();
-}
-
-extern "C" int stonk_attention_bwd(const void* q, const void* k, const void* v, int64_t ld,
-                                   const int64_t* attention_mask, const void* out, int64_t ldo, const void* dout,
-                                   int64_t lddo, const float* lse, float* delta_ws, void* dq, void* dk, int64_t ldd,
-                                   void* dv, int B, int NH, int S, int D, float scale, float drop_p, uint32_t seed,
-                                   void* stream) {
-  return attention_bwd_impl(true, q, k, v, ld, attention_mask, out, ldo, dout, lddo, lse, delta_ws, dq, dk, ldd, dv, B, NH, S,
-                            D, scale, drop_p, seed, stream);
-}
-
-extern "C" int stonk_attention_bwd_split(const void* q, const void* k, const void* v, int64_t ld,
-                                         const int64_t* attention_mask, const void* out, int64_t ldo, const void* dout,
-                                         int64_t lddo, const float* lse, float* delta_ws, void* dq, void* dk, int64_t ldd,
-                                         void* dv, int B, int NH, int S, int D, float scale, float drop_p, uint32_t seed,
-                                         void* stream) {
-  return attention_bwd_impl(false, q, k, v, ld, attention_mask, out, ldo, dout, lddo, lse, delta_ws, dq, dk, ldd, dv, B, NH,
-                            S, D, scale, drop_p, seed, stream);
 }

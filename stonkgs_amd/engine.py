@@ -96,7 +96,6 @@ class Engine:
         self.w4_fwd_down = True      # FFN-down forward: bias + dropout + residual (157 against 174 us alone)
         self.w4_gb = True            # dgrad through GELU, multiplying by the saved GELU' (172 against 200 us)
         self.w4_dgrad_resid = True   # dgrad into the residual stream: FFN-up, QKV (152 against 177 us)
-        self.attn_bwd_split = False  # (A/B) the two-kernel attention backward also for S = 256 / 512
         self.f16_logits = True      # label-sparse decoder logits in fp16 (False: fp32, 4 more bytes of HBM traffic per logit)
         self._wstream: Optional[torch.cuda.Stream] = None
         # The optimizer (grad-norm, AdamW, W^T refresh: ~2 ms of HBM-bound work) runs on a third stream; the next step's
@@ -367,8 +366,7 @@ class Engine:
         qkv = sv["qkv"]
         dqkv = self.buf(f"b.dqkv.{par}", (T, 3 * H))
         delta = self.buf("b.delta", (B, NH, seq), F32)
-        hip.call("stonk_attention_bwd_split" if self.attn_bwd_split else "stonk_attention_bwd", qkv.data_ptr(),
-                 qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H,
+        hip.call("stonk_attention_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H,
                  hip.ptr(mask), sv["ctx"].data_ptr(), H, dctx.data_ptr(), H, sv["lse"].data_ptr(), delta.data_ptr(),
                  dqkv.data_ptr(), dqkv.data_ptr() + 2 * H, 3 * H, dqkv.data_ptr() + 4 * H, B, NH, seq, 64,
                  1.0 / math.sqrt(64.0), p_att, self.seed(lidx, 1), st)

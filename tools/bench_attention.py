@@ -1,6 +1,6 @@
-"""Attention kernels alone at the step's shape (B 64, S 512, 12 heads, key-padding mask, dropout 0.1): forward, the
-one-kernel backward and the two-kernel backward, us per launch and algorithmic TFLOP/s (forward 4*S*S*64 per head,
-backward 10*S*S*64)."""
+"""Attention kernels alone at the step's shape (B 64, S 512, 12 heads, key-padding mask, dropout 0.1): forward and
+backward (dQ kernel + dK/dV kernel), us per launch and algorithmic TFLOP/s (forward 4*S*S*64 per head, backward
+10*S*S*64)."""
 import os
 import sys
 
@@ -51,6 +51,5 @@ def timeit(fn, n=20):
 fl = B * NH * S * S * 64
 t = timeit(fwd)
 print(f"forward: {t:.1f} us  {4 * fl / t / 1e6:.0f} TFLOP/s", flush=True)
-for name in ("stonk_attention_bwd", "stonk_attention_bwd_split"):
-    t = timeit(lambda: bwd(name))
-    print(f"{name}: {t:.1f} us  {10 * fl / t / 1e6:.0f} TFLOP/s (algorithmic)", flush=True)
+t = timeit(lambda: bwd("stonk_attention_bwd"))
+print(f"backward: {t:.1f} us  {10 * fl / t / 1e6:.0f} TFLOP/s (algorithmic)", flush=True)

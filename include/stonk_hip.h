@@ -35,13 +35,15 @@ int stonk_abi_version(void);
  * modifies the two users of `aux`: SAVE_PREACT (next to GELU) then stores gelu'(pre-activation) and GELU_BWD multiplies
  * by `aux` as is - the training step uses the pair, so the erf/exp of GELU' are evaluated once, in the forward epilogue.
  * m_dev / k_dev (nullable): effective M / K read from device memory at run time (label-sparse decoders).
+ * `kernel`: STONK_GEMM_AUTO (the launcher picks one of its three kernels from shape and epilogue) or an explicit
+ * STONK_GEMM_TILE128 / _WAVE8 / _WAVE4; an explicit kernel that cannot take the arguments is refused with STONK_ESHAPE.
  * Replaces torch addmm/mm of hf:models/bert/modeling_bert.py:154-156 (Q,K,V), :289-293 (attn out), :334-337
  * (FFN up + GELU), :347-351 (FFN down), :476-480 (head transform); ref:src/stonkgs/models/stonkgs_model.py:70-71
  * (text / entity decoders) and their autograd backward. */
 int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                        int flags, const float* bias, const void* resid, int64_t ldr, void* aux, int64_t ldaux,
                        float alpha, int split_k, const int* m_dev, const int* k_dev, float drop_p, uint32_t seed,
-                       void* stream);
+                       int kernel, void* stream);
 
 /* Weight / bias gradient straight from row-major activations: dW[M',N'] += alpha * dY[T,M']^T . X[T,N'],
  * db[M'] += alpha * colsum(dY) (nullable). M', N' % 128 == 0; rows of dY / X in [k, roundup64(k)) must read as zero when

@@ -24,10 +24,7 @@ EPI_SAVE_PREACT = 1 << 5
 EPI_GELU_BWD = 1 << 6
 EPI_DROPOUT = 1 << 7
 EPI_AUX_GRAD = 1 << 8   # aux = gelu'(pre-activation): stored by SAVE_PREACT (with GELU), multiplied in by GELU_BWD
-EPI_DEBUG_REGSTAGE = 1 << 16
-EPI_DEBUG_V1 = 1 << 17
-EPI_DEBUG_V2 = 1 << 18
-EPI_DEBUG_W4 = 1 << 20
+GEMM_AUTO, GEMM_TILE128, GEMM_WAVE8, GEMM_WAVE4 = 0, 1, 2, 3   # stonk_gemm_nt_bf16 `kernel`
 LN_DROPOUT = 1 << 0
 SMALL_TANH = 1
 SMALL_X_F32 = 16
@@ -37,7 +34,7 @@ _vp, _i32, _i64, _f32, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uin
 # name -> argtypes; every launcher returns int (0 ok, <0 bad argument, >0 hipError_t)
 _SIGNATURES = {
     "stonk_gemm_nt_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i64,
-                           _f32, _i32, _vp, _vp, _f32, _u32, _vp],
+                           _f32, _i32, _vp, _vp, _f32, _u32, _i32, _vp],
     "stonk_gemm_tn_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp],
     "stonk_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _f32, _u32, _vp],
     "stonk_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _u32, _f32, _u32,

@@ -299,8 +299,10 @@ int launch(const GemmArgs& a, int grid, hipStream_t st) {
 extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                   int M, int N, int K, int flags, const float* bias, const void* resid,
                                   int64_t ldr, void* aux, int64_t ldaux, float alpha, int split_k,
-                                  const int* m_dev, const int* k_dev, float drop_p, uint32_t seed, void* stream) {
+                                  const int* m_dev, const int* k_dev, float drop_p, uint32_t seed, int kernel,
+                                  void* stream) {
   STONK_CHECK_ARG(A && B && C, STONK_EINVAL);
+  STONK_CHECK_ARG(kernel >= STONK_GEMM_AUTO && kernel <= STONK_GEMM_WAVE4, STONK_EINVAL);
   STONK_CHECK_ARG(M >= 0 && N > 0 && K > 0, STONK_ESHAPE);
   STONK_CHECK_ARG(N % BN == 0 && K % BK == 0, STONK_ESHAPE);
   STONK_CHECK_ARG(split_k >= 1 && split_k <= K / BK, STONK_ESHAPE);
@@ -336,8 +338,7 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   const bool both_sides = (flags & STONK_EPI_GELU_BWD) && (flags & STONK_EPI_RESID);
   // (bias + dropout + residual has no constant-flag instance on the 256x256 kernel: it would spill)
   const bool bdr = (flags & STONK_EPI_DROPOUT) && (flags & STONK_EPI_RESID);
-  const bool big = M >= 1024 && N >= 1536 && out_mode != STONK_EPI_OUT_F32_ATOMIC && !both_sides && !bdr &&
-                   !(flags & STONK_EPI_DEBUG_SIDE_V1);
+  const bool big = M >= 1024 && N >= 1536 && out_mode != STONK_EPI_OUT_F32_ATOMIC && !both_sides && !bdr;
   // its epilogue moves 16-byte row segments: strides of every side operand must keep them aligned
   const bool v2_ok = ldc % 8 == 0 && (!(flags & STONK_EPI_BIAS) || alpha == 1.0f) &&  // bias rides in the accumulators
                       (!(flags & STONK_EPI_RESID) || (ldr % 8 == 0 && (uintptr_t)resid % 16 == 0)) &&
@@ -350,38 +351,36 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
                      (!(flags & STONK_EPI_RESID) || (ldr % 8 == 0 && (uintptr_t)resid % 16 == 0)) &&
                      (!(flags & (STONK_EPI_SAVE_PREACT | STONK_EPI_GELU_BWD)) ||
                       (ldaux % 8 == 0 && (uintptr_t)aux % 16 == 0));
-  // measured on MI355X (tools/bench_kernels.py): the four-wave kernel is the fastest of the three on every large launch
-  // of the step (QKV 127 us vs 148, FFN-up 155 vs 178, N = 768 outputs 50 / 143 vs 59 / 152)
-  // ... but not with an epilogue that READS a second [M,N] operand (residual, GELU' input): vmcnt retires in order, so
-  // each round's wait for its side loads also waits for the previous rounds' stores - with one workgroup per CU nothing
-  // hides that (in the step those launches ran 1.5-2x slower than on the 128x128 kernel, two workgroups per CU)
+  // AUTO, as measured in the training step (interleaved A/B, tools/ab_step.py):
+  //  * launches whose epilogue reads a second [M,N] operand (residual, saved GELU') go to the four-wave kernel: its
+  //    128x128 wave tiles halve the LDS bytes per flop and its epilogue requests the side operand a round ahead
+  //    (FFN-down / attention-output forward 157 against 174 us, dgrad + residual 152 against 177, dgrad through GELU' 172
+  //    against 200; -1.4 ms per step together);
+  //  * wide plain launches (fused QKV, FFN-up, the label-sparse decoders) stay on the eight-wave kernel: the four-wave one
+  //    is faster per launch there too (105 against 125 us) but draws more power, every other kernel of the step slows by
+  //    1-4 % and the step does not get shorter;
+  //  * everything else (N = 768 without a side operand, split-K atomics, small M) keeps the 128x128 tiles.
   const bool w4_side = (flags & (STONK_EPI_RESID | STONK_EPI_GELU_BWD)) != 0;
-  const bool w4_big = (M >= 1024 || m_dev) && out_mode != STONK_EPI_OUT_F32_ATOMIC && !w4_side &&
-                      !(flags & (STONK_EPI_DEBUG_V1 | STONK_EPI_DEBUG_V2 | STONK_EPI_DEBUG_REGSTAGE | STONK_EPI_DEBUG_SIDE_V1));
-  // ... yet the STEP is not faster with it (interleaved A/B, tools/ab_step.py: 42.75 ms against 42.45 with the weight
-  // gradients overlapping on the second stream, 43.2 against 43.8 without the overlap): what it gains on its own
-  // launches it takes from the overlapped weight-gradient kernels. Opt-in (STONK_W4=1 or the debug flag) until the
-  // weight gradients run on the same schedule.
-  const bool use_w4 = getenv("STONK_W4") != nullptr;   // (read per call: tools/ab_step.py env:STONK_W4 toggles it in-process)
-  if (w4_ok && ((w4_big && use_w4) || (flags & STONK_EPI_DEBUG_W4))) return stonk_gemm_w4_launch(a, out_mode, st);
-  if (v2_ok && !(flags & (STONK_EPI_DEBUG_V1 | STONK_EPI_DEBUG_REGSTAGE)) && (big || (flags & STONK_EPI_DEBUG_V2)))
+  int k = kernel;
+  if (k == STONK_GEMM_AUTO)
+    k = (w4_ok && w4_side && M >= 1024 && out_mode == STONK_EPI_OUT_BF16) ? STONK_GEMM_WAVE4
+        : (v2_ok && big)                                                     ? STONK_GEMM_WAVE8
+                                                                             : STONK_GEMM_TILE128;
+  if (k == STONK_GEMM_WAVE4) {
+    STONK_CHECK_ARG(w4_ok, STONK_ESHAPE);
+    return stonk_gemm_w4_launch(a, out_mode, st);
+  }
+  if (k == STONK_GEMM_WAVE8) {
+    STONK_CHECK_ARG(v2_ok, STONK_ESHAPE);
     return stonk_gemm256_launch(a, out_mode, st);
+  }
   const long tiles = (long)((M + BM - 1) / BM) * (N / BN) * split_k;
   // with a device-side row count the grid is capped and blocks walk the tiles that exist at run time
   const long cap = m_dev ? 4096 : tiles;
   const int grid = (int)(tiles < cap ? tiles : cap);
-  const bool glds = !(flags & STONK_EPI_DEBUG_REGSTAGE);
   constexpr int Bi = STONK_EPI_BIAS, G = STONK_EPI_GELU, SV = STONK_EPI_SAVE_PREACT, GB = STONK_EPI_GELU_BWD,
                 R = STONK_EPI_RESID, D = STONK_EPI_DROPOUT, AG = STONK_EPI_AUX_GRAD;
   const int epi = flags & (Bi | G | SV | GB | R | D | AG);
-  if (!glds) {
-    switch (out_mode) {
-      case STONK_EPI_OUT_BF16: return launch<0, false, -1>(a, grid, st);
-      case STONK_EPI_OUT_F32: return launch<1, false, -1>(a, grid, st);
-      case STONK_EPI_OUT_F16: return launch<3, false, -1>(a, grid, st);
-      default: return launch<2, false, -1>(a, grid, st);
-    }
-  }
   if (out_mode == STONK_EPI_OUT_F32_ATOMIC) return launch<2, true, -1>(a, grid, st);
   if (out_mode == STONK_EPI_OUT_F16) return launch<3, true, 0>(a, grid, st);
   if (out_mode == STONK_EPI_OUT_F32) return epi == 0 ? launch<1, true, 0>(a, grid, st) : launch<1, true, -1>(a, grid, st);
@@ -399,4 +398,4 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   }
 }
 
-extern "C" int stonk_abi_version(void) { return 1; }
+extern "C" int stonk_abi_version(void) { return 2; }

@@ -521,19 +521,7 @@ int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, hipStream_t st) {
   if (out_mode == 1) return epi == 0 ? launch_w4<1, 0>(a, grid, st) : launch_w4<1, -1>(a, grid, st);
   if (out_mode == 2) return launch_w4<2, 0>(a, grid, st);
   switch (epi) {   // the combinations the STonKGs step uses are compiled with constant flags
-    case 0: {
-      static const int var = getenv("STONK_W4_VAR") ? atoi(getenv("STONK_W4_VAR")) : 0;   // timing experiments
-      switch (var) {
-        case 1: return launch_w4<0, 0, 1>(a, grid, st);
-        case 4: return launch_w4<0, 0, 4>(a, grid, st);
-        case 8: return launch_w4<0, 0, 8>(a, grid, st);
-        case 12: return launch_w4<0, 0, 12>(a, grid, st);
-        case 13: return launch_w4<0, 0, 13>(a, grid, st);
-        case 16: return launch_w4<0, 0, 16>(a, grid, st);
-        case 32: return launch_w4<0, 0, 32>(a, grid, st);
-        default: return launch_w4<0, 0>(a, grid, st);
-      }
-    }
+    case 0: return launch_w4<0, 0>(a, grid, st);
     case B: return launch_w4<0, B>(a, grid, st);
     case B | G: return launch_w4<0, B | G>(a, grid, st);
     case B | G | SV: return launch_w4<0, B | G | SV>(a, grid, st);

@@ -644,7 +644,7 @@ extern "C" int stonk_layernorm_fwd(const void* x, const float* gamma, const floa
   if (rows == 0) return STONK_OK;
   const uint32_t thr = stonk_drop_thr32(drop_p);
   const float ds = 1.f / (1.f - drop_p);
-  const bool generic_only = getenv("STONK_LN_V1") != nullptr;   // A/B switch: the generic kernels for every H
+  const bool generic_only = false;   // (the lane-owned-column kernels serve H = 512 / 768 / 1024; other widths take the generic ones)
   const bool drop = (flags & STONK_LN_DROPOUT) != 0;
 #define LN_FWD_LANE(EPL)                                                                                                \
   do {                                                                                                                  \
@@ -694,7 +694,7 @@ extern "C" int stonk_layernorm_bwd(const void* dy, const void* x, const float* m
     else if (dout) LN_BWD_LANE(EPL, false, true);           \
     else LN_BWD_LANE(EPL, false, false);                    \
   } while (0)
-  const bool generic_only = getenv("STONK_LN_V1") != nullptr;   // A/B switch: the generic kernel for every H
+  const bool generic_only = false;
   if (H == 768 && !generic_only) LN_BWD_LANE_H(12);
   else if (H == 1024 && !generic_only) LN_BWD_LANE_H(16);
   else if (H == 512 && !generic_only) LN_BWD_LANE_H(8);

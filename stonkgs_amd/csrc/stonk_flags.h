@@ -17,11 +17,12 @@
 #define STONK_EPI_AUX_GRAD (1 << 8)     /* aux holds gelu'(pre-activation), not the pre-activation: SAVE_PREACT (with GELU) \
                                            stores it, GELU_BWD multiplies by it - the erf/exp of the backward epilogue \
                                            are paid once, in the forward one, which evaluates them anyway */
-#define STONK_EPI_DEBUG_REGSTAGE (1 << 16) /* A/B test: register staging instead of LDS-DMA (128x128 kernel) */
-#define STONK_EPI_DEBUG_V1 (1 << 17)       /* force the 128x128 two-barrier kernel */
-#define STONK_EPI_DEBUG_V2 (1 << 18)       /* force the persistent 256x256 kernel */
-#define STONK_EPI_DEBUG_SIDE_V1 (1 << 19)  /* A/B test: keep side-operand epilogues on the 128x128 kernel */
-#define STONK_EPI_DEBUG_W4 (1 << 20)       /* force the four-wave 256x256 kernel (gemm_w4.hip) */
+// --- stonk_gemm_nt_bf16 `kernel`: which of the three NT kernels runs the launch ---
+#define STONK_GEMM_AUTO 0     /* the launcher's choice, from the shape and the epilogue (measured on MI355X, gemm_bf16.hip) */
+#define STONK_GEMM_TILE128 1  /* 128x128x64 tiles, two workgroups per CU, a grid the hardware schedules dynamically: the \
+                                 form to ask for when another stream (a collective) holds CUs during the launch */
+#define STONK_GEMM_WAVE8 2    /* persistent 256x256x64, eight waves, one workgroup per CU (gemm256.hip) */
+#define STONK_GEMM_WAVE4 3    /* persistent 256x256x64, four waves with 128x128 wave tiles (gemm_w4.hip) */
 // --- stonk_layernorm_* `flags` ---
 #define STONK_LN_DROPOUT (1 << 0)
 // --- stonk_small_linear_* `act` ---

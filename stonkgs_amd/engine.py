@@ -87,15 +87,12 @@ class Engine:
         # stream (dgrad through GELU) then takes the 128x128 kernel, whose grid the hardware schedules dynamically.
         self.comm_overlap = False
         self.decoder_dgrad_256 = True
-        # Launches with a second [M,N] operand on the four-wave NT kernel (its epilogue requests the side operand one round
-        # ahead): interleaved A/B in the step, each switch alone -0.54 / -0.17 / -0.72 ms, all three 37.1 -> 35.9 ms. The
-        # backward ones are persistent launches: not beside a running all-reduce (comm_overlap, tools/hog_test.py).
-        self.w4_fwd_out = True       # attention-output projection forward (same time alone, -0.2 ms in the step)
-        self.w4_dgrad_out = False    # (A/B) attention-output projection dgrad
-        self.w4_fwd_up = False       # (A/B) encoder FFN-up forward: bias + GELU + saved GELU'
-        self.w4_fwd_down = True      # FFN-down forward: bias + dropout + residual (157 against 174 us alone)
-        self.w4_gb = True            # dgrad through GELU, multiplying by the saved GELU' (172 against 200 us)
-        self.w4_dgrad_resid = True   # dgrad into the residual stream: FFN-up, QKV (152 against 177 us)
+        # Which of the library's three NT kernels runs a launch is the LIBRARY's choice (STONK_GEMM_AUTO: from shape and
+        # epilogue, stonk_gemm_nt_bf16) - except where the engine knows what the library cannot: that an all-reduce is
+        # running beside backward (comm_overlap -> the dynamically scheduled 128x128 kernel for the persistent launches).
+        # `kernel_for` lets a tool pin a site for an A/B (tools/ab_step.py): "qkv", "attn_out", "ffn_up", "ffn_down",
+        # "dgrad_gelu", "dgrad_resid", "dgrad_attn_out" -> hip.GEMM_*.
+        self.kernel_for: Dict[str, int] = {}
         self.f16_logits = True      # label-sparse decoder logits in fp16 (False: fp32, 4 more bytes of HBM traffic per logit)
         self._wstream: Optional[torch.cuda.Stream] = None
         # The optimizer (grad-norm, AdamW, W^T refresh: ~2 ms of HBM-bound work) runs on a third stream; the next step's
@@ -110,7 +107,6 @@ class Engine:
         self.tn_v1 = bool(os.environ.get("STONK_TN_V1"))
         self.tn_cus = int(os.environ.get("STONK_TN_CUS", "160"))
         self.tn_min_tiles = 36 if os.environ.get("STONK_TN_SMALL") else 100
-        self.fwd_w4 = bool(os.environ.get("STONK_FWD_W4"))
 
     # ------------------------------------------------------------------ plumbing
     def buf(self, name: str, shape, dtype=BF16, zero=False) -> torch.Tensor:
@@ -175,7 +171,7 @@ class Engine:
             raise IndexError("; ".join(msgs))
 
     def gemm(self, A, B, C, M, N, K, flags=0, bias=None, resid=None, aux=None, alpha=1.0, split_k=1, m_dev=None,
-             k_dev=None, drop_p=0.0, seed=0):
+             k_dev=None, drop_p=0.0, seed=0, kernel=hip.GEMM_AUTO):
         st = hip.stream_ptr()
         timed = self.gemm_timer is not None
         if timed:
@@ -185,7 +181,7 @@ class Engine:
         hip.call("stonk_gemm_nt_bf16", A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), C.stride(0),
                  M, N, K, flags, hip.ptr(bias), hip.ptr(resid), 0 if resid is None else resid.stride(0), hip.ptr(aux),
                  0 if aux is None else aux.stride(0), alpha, split_k, hip.ptr(m_dev), hip.ptr(k_dev), drop_p,
-                 seed & 0xFFFFFFFF, st)
+                 seed & 0xFFFFFFFF, kernel, st)
         if timed:
             e1.record()
             self.gemm_timer.records.append(("nt", e0, e1, M, N, K, m_dev, k_dev))
@@ -234,6 +230,14 @@ class Engine:
                  hip.ptr(rows_dev), hip.stream_ptr())
         return out
 
+    def _kernel(self, site: str, persistent_in_backward: bool = False) -> int:
+        """NT kernel of a launch site: a tool's pin, else the dynamically scheduled kernel for a backward launch that
+        would otherwise be persistent while a collective holds CUs, else the library's own choice."""
+        k = self.kernel_for.get(site)
+        if k is not None:
+            return k
+        return hip.GEMM_TILE128 if (persistent_in_backward and self.comm_overlap) else hip.GEMM_AUTO
+
     def seed(self, layer: int, site: int) -> int:
         return (self.seed_base * 0x9E3779B1 + layer * 64 + site) & 0xFFFFFFFF
 
@@ -268,9 +272,8 @@ class Engine:
         w = S.bf16_view
         f = S.view
         qkv = self.buf(f"{tag}.qkv", (T, 3 * H))
-        w4 = hip.EPI_DEBUG_W4 if self.fwd_w4 else 0   # (development switch, tools/fwd_w4_probe.py)
-        self.gemm(x, w(prefix + ".attention.self.qkv.weight"), qkv, T, 3 * H, H, flags=hip.EPI_BIAS | w4,
-                  bias=f(prefix + ".attention.self.qkv.bias"))
+        self.gemm(x, w(prefix + ".attention.self.qkv.weight"), qkv, T, 3 * H, H, flags=hip.EPI_BIAS,
+                  bias=f(prefix + ".attention.self.qkv.bias"), kernel=self._kernel("qkv"))
         ctx = self.buf(f"{tag}.ctx", (T, H))
         lse = self.buf(f"{tag}.lse", (B, NH, seq), F32)
         hip.call("stonk_attention_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H,
@@ -278,9 +281,9 @@ class Engine:
                  self.seed(lidx, 1), st)
         s1 = self.buf(f"{tag}.s1", (T, H))
         fl = hip.EPI_BIAS | hip.EPI_RESID | (hip.EPI_DROPOUT if p_hid > 0 else 0)
-        self.gemm(ctx, w(prefix + ".attention.output.dense.weight"), s1, T, H, H,
-                  flags=fl | (hip.EPI_DEBUG_W4 if self.w4_fwd_out else 0),
-                  bias=f(prefix + ".attention.output.dense.bias"), resid=x, drop_p=p_hid, seed=self.seed(lidx, 2))
+        self.gemm(ctx, w(prefix + ".attention.output.dense.weight"), s1, T, H, H, flags=fl,
+                  bias=f(prefix + ".attention.output.dense.bias"), resid=x, drop_p=p_hid, seed=self.seed(lidx, 2),
+                  kernel=self._kernel("attn_out"))
         h1 = self.buf(f"{tag}.h1", (T, H))
         st1 = self.buf(f"{tag}.st1", (2, T), F32)
         hip.call("stonk_layernorm_fwd", s1.data_ptr(), f(prefix + ".attention.output.LayerNorm.weight").data_ptr(),
@@ -288,16 +291,13 @@ class Engine:
                  st1[1].data_ptr(), T, H, cfg.layer_norm_eps, 0, 0.0, 0, st)
         g = self.buf(f"{tag}.g", (T, I))
         u = self.buf(f"{tag}.u", (T, I)) if save is not None else None
-        fl = hip.EPI_BIAS | hip.EPI_GELU | ((hip.EPI_SAVE_PREACT | hip.EPI_AUX_GRAD) if save is not None else w4)
-        if save is not None and self.w4_fwd_up:
-            fl |= hip.EPI_DEBUG_W4
+        fl = hip.EPI_BIAS | hip.EPI_GELU | ((hip.EPI_SAVE_PREACT | hip.EPI_AUX_GRAD) if save is not None else 0)
         self.gemm(h1, w(prefix + ".intermediate.dense.weight"), g, T, I, H, flags=fl,
-                  bias=f(prefix + ".intermediate.dense.bias"), aux=u)
+                  bias=f(prefix + ".intermediate.dense.bias"), aux=u, kernel=self._kernel("ffn_up"))
         s2 = self.buf(f"{tag}.s2", (T, H))
         fl = hip.EPI_BIAS | hip.EPI_RESID | (hip.EPI_DROPOUT if p_hid > 0 else 0)
-        self.gemm(g, w(prefix + ".output.dense.weight"), s2, T, H, I, flags=fl | (hip.EPI_DEBUG_W4 if self.w4_fwd_down else 0),
-                  bias=f(prefix + ".output.dense.bias"),
-                  resid=h1, drop_p=p_hid, seed=self.seed(lidx, 3))
+        self.gemm(g, w(prefix + ".output.dense.weight"), s2, T, H, I, flags=fl, bias=f(prefix + ".output.dense.bias"),
+                  resid=h1, drop_p=p_hid, seed=self.seed(lidx, 3), kernel=self._kernel("ffn_down"))
         y = self.buf(f"{prefix}.y" if save is not None else f"tmp.y{lidx & 1}", (T, H))
         st2 = self.buf(f"{tag}.st2", (2, T), F32)
         hip.call("stonk_layernorm_fwd", s2.data_ptr(), f(prefix + ".output.LayerNorm.weight").data_ptr(),
@@ -335,17 +335,14 @@ class Engine:
         # ---- FFN down: wgrad, bias grad, dgrad fused with GELU'
         self.wgrad(df, sv["g"], g_(prefix + ".output.dense.weight"), g_(prefix + ".output.dense.bias"), H, I, T)
         du = self.buf(f"b.du.{par}", (T, I))
-        self.gemm(df, wt[prefix + ".output.dense.weight"], du, T, I, H,
-                  flags=hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD | (hip.EPI_DEBUG_V1 if self.comm_overlap else
-                                                                (hip.EPI_DEBUG_W4 if self.w4_gb else 0)),
-                  aux=sv["u"])
+        self.gemm(df, wt[prefix + ".output.dense.weight"], du, T, I, H, flags=hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD,
+                  aux=sv["u"], kernel=self._kernel("dgrad_gelu", True))
         # ---- FFN up
         self.wgrad(du, sv["h1"], g_(prefix + ".intermediate.dense.weight"), g_(prefix + ".intermediate.dense.bias"), I, H,
                    T)
         dh1 = self.buf("b.dh1", (T, H))
-        self.gemm(du, wt[prefix + ".intermediate.dense.weight"], dh1, T, H, I,
-                  flags=hip.EPI_RESID | (hip.EPI_DEBUG_W4 if self.w4_dgrad_resid and not self.comm_overlap else 0),
-                  resid=ds2)
+        self.gemm(du, wt[prefix + ".intermediate.dense.weight"], dh1, T, H, I, flags=hip.EPI_RESID, resid=ds2,
+                  kernel=self._kernel("dgrad_resid", True))
         # ---- LN1 backward
         ds1 = self.buf(f"b.ds1.{par}", (T, H))
         da = self.buf(f"b.da.{par}", (T, H)) if p_hid > 0 else None
@@ -360,8 +357,7 @@ class Engine:
         self.wgrad(da, sv["ctx"], g_(prefix + ".attention.output.dense.weight"),
                    g_(prefix + ".attention.output.dense.bias"), H, H, T)
         dctx = self.buf("b.dctx", (T, H))
-        self.gemm(da, wt[prefix + ".attention.output.dense.weight"], dctx, T, H, H,
-                  flags=hip.EPI_DEBUG_W4 if self.w4_dgrad_out and not self.comm_overlap else 0)
+        self.gemm(da, wt[prefix + ".attention.output.dense.weight"], dctx, T, H, H, kernel=self._kernel("dgrad_attn_out"))
         # ---- attention core
         qkv = sv["qkv"]
         dqkv = self.buf(f"b.dqkv.{par}", (T, 3 * H))
@@ -374,9 +370,8 @@ class Engine:
         self.wgrad(dqkv, sv["x"], g_(prefix + ".attention.self.qkv.weight"), g_(prefix + ".attention.self.qkv.bias"),
                    3 * H, H, T)
         dx = self.buf(f"b.dx{lidx & 1}", (T, H))
-        self.gemm(dqkv, wt[prefix + ".attention.self.qkv.weight"], dx, T, H, 3 * H,
-                  flags=hip.EPI_RESID | (hip.EPI_DEBUG_W4 if self.w4_dgrad_resid and not self.comm_overlap else 0),
-                  resid=ds1)
+        self.gemm(dqkv, wt[prefix + ".attention.self.qkv.weight"], dx, T, H, 3 * H, flags=hip.EPI_RESID, resid=ds1,
+                  kernel=self._kernel("dgrad_resid", True))
         if self._wstream is not None and self.overlap_wgrad:
             done = torch.cuda.Event()
             done.record(self._wstream)
@@ -573,8 +568,8 @@ class Engine:
             # launched: a persistent launch would wait for the CUs RCCL holds, tools/hog_test.py)
             if (self.decoder_dgrad_256 and npad >= 16384 and cap >= 1024 and H % 256 == 0
                     and not (self.comm_overlap and nm != "ent")):
-                self.gemm(h["dl"], wt[wname], dhs, cap, H, npad, flags=hip.EPI_OUT_F32_ATOMIC | hip.EPI_DEBUG_V2,
-                          split_k=8, m_dev=h["cnt"], alpha=gscale)
+                self.gemm(h["dl"], wt[wname], dhs, cap, H, npad, flags=hip.EPI_OUT_F32_ATOMIC, split_k=8, m_dev=h["cnt"],
+                          alpha=gscale, kernel=hip.GEMM_WAVE8)
             else:
                 self.gemm(h["dl"], wt[wname], dhs, cap, H, npad, flags=hip.EPI_OUT_F32_ATOMIC,
                           split_k=max(1, min(16, npad // 2048)), m_dev=h["cnt"], alpha=gscale)

@@ -8,14 +8,15 @@ pytestmark = pytest.mark.gpu
 
 
 def _gemm(hip, A, B, out_dtype=torch.bfloat16, M=None, flags=0, bias=None, resid=None, aux=None, alpha=1.0,
-          split_k=1, C=None, m_dev=None, k_dev=None, drop_p=0.0, seed=0):
+          split_k=1, C=None, m_dev=None, k_dev=None, drop_p=0.0, seed=0, kernel=0):
     M = A.shape[0] if M is None else M
     N, K = B.shape
     if C is None:
         C = torch.empty(M, N, device=A.device, dtype=out_dtype)
     hip.call("stonk_gemm_nt_bf16", hip.ptr(A), A.stride(0), hip.ptr(B), B.stride(0), hip.ptr(C), C.stride(0), M, N, K,
              flags, hip.ptr(bias), hip.ptr(resid), 0 if resid is None else resid.stride(0), hip.ptr(aux),
-             0 if aux is None else aux.stride(0), alpha, split_k, hip.ptr(m_dev), hip.ptr(k_dev), drop_p, seed, hip.stream_ptr())
+             0 if aux is None else aux.stride(0), alpha, split_k, hip.ptr(m_dev), hip.ptr(k_dev), drop_p, seed,
+             kernel, hip.stream_ptr())
     return C
 
 
@@ -24,7 +25,8 @@ def _rand(shape, scale=1.0, seed=0):
     return (torch.randn(shape, device="cuda", generator=g) * scale).to(torch.bfloat16)
 
 
-KERNELS = {"v1": 1 << 17, "v1_regstage": 1 << 16, "v2_256": 1 << 18, "w4_256": 1 << 20, "auto": 0}
+T128, WAVE8, WAVE4 = 1, 2, 3   # stonk_gemm_nt_bf16 `kernel` (STONK_GEMM_TILE128 / _WAVE8 / _WAVE4; 0 = AUTO)
+KERNELS = {"v1": T128, "v2_256": WAVE8, "w4_256": WAVE4, "auto": 0}
 
 
 @pytest.mark.parametrize("kernel", list(KERNELS))
@@ -34,14 +36,18 @@ def test_gemm_plain_bf16_and_f32(hip, M, N, K, kernel):
     A, B = _rand((M, K), seed=1), _rand((N, K), seed=2)
     ref = A.float() @ B.float().t()
     dbg = KERNELS[kernel]
-    out32 = _gemm(hip, A, B, torch.float32, flags=hip.EPI_OUT_F32 | dbg)
+    if kernel == "w4_256" and (K // 64) % 2:   # the four-wave kernel walks K tiles in pairs: an explicit request is refused
+        with pytest.raises(hip.StonkHipError, match="-2"):
+            _gemm(hip, A, B, torch.float32, flags=hip.EPI_OUT_F32, kernel=dbg)
+        return
+    out32 = _gemm(hip, A, B, torch.float32, flags=hip.EPI_OUT_F32, kernel=dbg)
     torch.cuda.synchronize()
     err = (out32 - ref).abs().max().item()
     assert err <= 1e-3 * math.sqrt(K), f"fp32-out max err {err}"
-    out16 = _gemm(hip, A, B, torch.bfloat16, flags=hip.EPI_OUT_BF16 | dbg)
+    out16 = _gemm(hip, A, B, torch.bfloat16, flags=hip.EPI_OUT_BF16, kernel=dbg)
     torch.testing.assert_close(out16.float(), ref, rtol=1.6e-2, atol=1e-2 * math.sqrt(K) / 8)
     if kernel in ("v1", "v2_256", "auto"):   # fp16 output (label-sparse logits): the fp32 result rounded once, to 11 bits
-        outh = _gemm(hip, A, B, torch.float16, flags=hip.EPI_OUT_F16 | dbg)
+        outh = _gemm(hip, A, B, torch.float16, flags=hip.EPI_OUT_F16, kernel=dbg)
         torch.testing.assert_close(outh.float(), out32.half().float(), rtol=1e-3, atol=1e-3)
 
 
@@ -55,7 +61,7 @@ def test_gemm_f16_output_saturates_and_takes_no_epilogue(hip):
     bias = torch.zeros(128, device="cuda")
     rc = hip.lib().stonk_gemm_nt_bf16(hip.ptr(A), 64, hip.ptr(B), 64, hip.ptr(C), 128, 128, 128, 64,
                                       hip.EPI_OUT_F16 | hip.EPI_BIAS, hip.ptr(bias), 0, 0, 0, 0, 1.0, 1, 0, 0, 0.0, 0,
-                                      hip.stream_ptr())
+                                      0, hip.stream_ptr())
     assert rc == -1
 
 
@@ -68,51 +74,51 @@ def test_gemm_asymmetric_identity(hip):
     torch.testing.assert_close(out, B.float().t().contiguous(), rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("dbg", [1 << 17, 1 << 18, 1 << 20])
+@pytest.mark.parametrize("dbg", [T128, WAVE8, WAVE4])
 def test_gemm_epilogues(hip, dbg):
-    M, N, K = (304, 256, 256) if dbg == 1 << 20 else (300, 256, 192)   # four-wave kernel: K tiles in pairs, M % 8
+    M, N, K = (304, 256, 256) if dbg == WAVE4 else (300, 256, 192)   # four-wave kernel: K tiles in pairs, M % 8
     A, B = _rand((M, K), 0.5, 3), _rand((N, K), 0.5, 4)
     bias = torch.randn(N, device="cuda")
     resid = _rand((M, N), 1.0, 5)
     pre = A.float() @ B.float().t() + bias
     # bias + gelu + saved pre-activation
     aux = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
-    out = _gemm(hip, A, B, flags=dbg | hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT, bias=bias, aux=aux)
+    out = _gemm(hip, A, B, flags=hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT, kernel=dbg, bias=bias, aux=aux)
     torch.testing.assert_close(aux.float(), pre, rtol=1e-2, atol=2e-2)
     torch.testing.assert_close(out.float(), torch.nn.functional.gelu(pre), rtol=1e-2, atol=2e-2)
     # bias + residual
-    out = _gemm(hip, A, B, flags=dbg | hip.EPI_BIAS | hip.EPI_RESID, bias=bias, resid=resid)
+    out = _gemm(hip, A, B, flags=hip.EPI_BIAS | hip.EPI_RESID, kernel=dbg, bias=bias, resid=resid)
     torch.testing.assert_close(out.float(), pre + resid.float(), rtol=1e-2, atol=3e-2)
     # gelu backward: result * gelu'(aux)
     u = _rand((M, N), 1.0, 6)
-    out = _gemm(hip, A, B, flags=dbg | hip.EPI_GELU_BWD, aux=u)
+    out = _gemm(hip, A, B, flags=hip.EPI_GELU_BWD, kernel=dbg, aux=u)
     uf = u.float().requires_grad_(True)
     (gp,) = torch.autograd.grad(torch.nn.functional.gelu(uf).sum(), uf)
     torch.testing.assert_close(out.float(), (A.float() @ B.float().t()) * gp, rtol=1e-2, atol=3e-2)
     # the same pair with STONK_EPI_AUX_GRAD: forward leaves gelu'(pre-activation) in aux, backward multiplies by aux as is
     aux2 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
-    out = _gemm(hip, A, B, flags=dbg | hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT | hip.EPI_AUX_GRAD, bias=bias,
+    out = _gemm(hip, A, B, flags=hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT | hip.EPI_AUX_GRAD, kernel=dbg, bias=bias,
                 aux=aux2)
     pf = pre.clone().requires_grad_(True)
     (gpre,) = torch.autograd.grad(torch.nn.functional.gelu(pf).sum(), pf)
     torch.testing.assert_close(aux2.float(), gpre, rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(out.float(), torch.nn.functional.gelu(pre), rtol=1e-2, atol=2e-2)
-    out = _gemm(hip, A, B, flags=dbg | hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD, aux=u)
+    out = _gemm(hip, A, B, flags=hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD, kernel=dbg, aux=u)
     torch.testing.assert_close(out.float(), (A.float() @ B.float().t()) * u.float(), rtol=1e-2, atol=3e-2)
     # the modifier alone is refused
     C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     rc = hip.lib().stonk_gemm_nt_bf16(hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, M, N, K, hip.EPI_AUX_GRAD, 0, 0, 0, 0,
-                                      0, 1.0, 1, 0, 0, 0.0, 0, hip.stream_ptr())
+                                      0, 1.0, 1, 0, 0, 0.0, 0, 0, hip.stream_ptr())
     assert rc == -1
 
 
-@pytest.mark.parametrize("dbg,M,N,K,sk", [(1 << 17, 256, 128, 2048, 8), (1 << 18, 768, 768, 8192, 7),
-                                          (1 << 20, 768, 768, 8192, 8), (1 << 20, 304, 512, 4096, 16),
-                                          (1 << 18, 300, 256, 4096, 32), (0, 3072, 768, 32768, 8)])
+@pytest.mark.parametrize("dbg,M,N,K,sk", [(T128, 256, 128, 2048, 8), (WAVE8, 768, 768, 8192, 7),
+                                          (WAVE4, 768, 768, 8192, 8), (WAVE4, 304, 512, 4096, 16),
+                                          (WAVE8, 300, 256, 4096, 32), (0, 3072, 768, 32768, 8)])
 def test_gemm_splitk_atomic_accumulates(hip, dbg, M, N, K, sk):
     A, B = _rand((M, K), 0.3, 7), _rand((N, K), 0.3, 8)
     C = torch.ones(M, N, device="cuda")
-    _gemm(hip, A, B, flags=dbg | hip.EPI_OUT_F32_ATOMIC, split_k=sk, C=C)
+    _gemm(hip, A, B, flags=hip.EPI_OUT_F32_ATOMIC, kernel=dbg, split_k=sk, C=C)
     torch.testing.assert_close(C, 1.0 + A.float() @ B.float().t(), rtol=1e-4, atol=2e-3 * (K / 2048) ** 0.5)
 
 
@@ -123,7 +129,7 @@ def test_gemm256_device_counts_and_races(hip):
     A, B = _rand((M, K), 0.5, 21), _rand((N, K), 0.5, 22)
     m_dev = torch.tensor([2432 - 5], device="cuda", dtype=torch.int32)
     C = torch.full((M, N), -7.0, device="cuda")
-    _gemm(hip, A, B, flags=hip.EPI_DEBUG_V2 | hip.EPI_OUT_F32, C=C, m_dev=m_dev)
+    _gemm(hip, A, B, flags=hip.EPI_OUT_F32, C=C, m_dev=m_dev, kernel=WAVE8)
     ref = A[:2427].float() @ B.float().t()
     torch.testing.assert_close(C[:2427], ref, rtol=1e-4, atol=2e-3)
     assert (C[2427:] == -7.0).all()
@@ -132,38 +138,37 @@ def test_gemm256_device_counts_and_races(hip):
     A2, B2 = _rand((1024, 4096), 0.5, 23), _rand((768, 4096), 0.5, 24)
     A2[:, 300:] = 0  # what the zero-filling transpose guarantees up to the 64 round-up
     C2 = torch.zeros(1024, 768, device="cuda")
-    _gemm(hip, A2, B2, flags=hip.EPI_DEBUG_V2 | hip.EPI_OUT_F32_ATOMIC, split_k=4, C=C2, k_dev=k_dev)
+    _gemm(hip, A2, B2, flags=hip.EPI_OUT_F32_ATOMIC, split_k=4, C=C2, k_dev=k_dev, kernel=WAVE8)
     torch.testing.assert_close(C2, A2[:, :320].float() @ B2[:, :320].float().t(), rtol=1e-4, atol=2e-3)
     # race screen
     A3, B3 = _rand((8192, 768), 1.0, 25), _rand((3072, 768), 0.05, 26)
-    first = _gemm(hip, A3, B3, flags=hip.EPI_DEBUG_V2)
+    first = _gemm(hip, A3, B3, kernel=WAVE8)
     torch.testing.assert_close(first.float(), A3.float() @ B3.float().t(), rtol=2e-2, atol=2e-2)
     for _ in range(20):
-        assert torch.equal(_gemm(hip, A3, B3, flags=hip.EPI_DEBUG_V2), first)
+        assert torch.equal(_gemm(hip, A3, B3, kernel=WAVE8), first)
 
 
 def test_gemm_w4_device_rows_races_and_fused_epilogue(hip):
     """Four-wave 256x256 kernel: device-side M with a ragged last tile, many work items per workgroup, bit-identical
     repeats (a ring-slot race would show as rare differing tiles), and the bias + dropout + residual epilogue."""
-    W4 = 1 << 20
     M, N, K = 16384, 768, 1024
     A, B = _rand((M, K), 0.5, 31), _rand((N, K), 0.5, 32)
     m_dev = torch.tensor([2432 - 5], device="cuda", dtype=torch.int32)
     C = torch.full((M, N), -7.0, device="cuda")
-    _gemm(hip, A, B, flags=W4 | hip.EPI_OUT_F32, C=C, m_dev=m_dev)
+    _gemm(hip, A, B, flags=hip.EPI_OUT_F32, C=C, m_dev=m_dev, kernel=WAVE4)
     torch.testing.assert_close(C[:2427], A[:2427].float() @ B.float().t(), rtol=1e-4, atol=2e-3)
     assert (C[2427:] == -7.0).all()
     A3, B3 = _rand((8192, 768), 1.0, 35), _rand((3072, 768), 0.05, 36)
-    first = _gemm(hip, A3, B3, flags=W4)
+    first = _gemm(hip, A3, B3, kernel=WAVE4)
     torch.testing.assert_close(first.float(), A3.float() @ B3.float().t(), rtol=2e-2, atol=2e-2)
     for _ in range(20):
-        assert torch.equal(_gemm(hip, A3, B3, flags=W4), first)
+        assert torch.equal(_gemm(hip, A3, B3, kernel=WAVE4), first)
     # N = 768 output with K = 3072 (FFN down): bias + dropout + residual, compared through the kept elements
     A4, B4 = _rand((4096, 3072), 0.5, 37), _rand((768, 3072), 0.05, 38)
     bias = torch.randn(768, device="cuda")
     resid = _rand((4096, 768), 1.0, 39)
-    fl = W4 | hip.EPI_BIAS | hip.EPI_RESID | hip.EPI_DROPOUT
-    out = _gemm(hip, A4, B4, flags=fl, bias=bias, resid=resid, drop_p=0.1, seed=77).float()
+    fl = hip.EPI_BIAS | hip.EPI_RESID | hip.EPI_DROPOUT
+    out = _gemm(hip, A4, B4, flags=fl, bias=bias, resid=resid, drop_p=0.1, seed=77, kernel=WAVE4).float()
     pre = A4.float() @ B4.float().t() + bias
     delta = out - resid.float()                      # = keep ? pre / 0.9 : 0
     kept = (delta.abs() > 1e-3) | (pre.abs() < 1e-2)
@@ -171,7 +176,7 @@ def test_gemm_w4_device_rows_races_and_fused_epilogue(hip):
     torch.testing.assert_close(torch.where(kept, delta, torch.zeros_like(delta)),
                                torch.where(kept, pre / 0.9, torch.zeros_like(pre)), rtol=3e-2, atol=6e-2)
     # same mask from the 128x128 kernel (one dropout stream per (seed, row, column), whatever the tiling)
-    out_v1 = _gemm(hip, A4, B4, flags=(1 << 17) | hip.EPI_BIAS | hip.EPI_RESID | hip.EPI_DROPOUT, bias=bias,
+    out_v1 = _gemm(hip, A4, B4, flags=hip.EPI_BIAS | hip.EPI_RESID | hip.EPI_DROPOUT, kernel=T128, bias=bias,
                    resid=resid, drop_p=0.1, seed=77).float()
     assert ((out_v1 - resid.float()).abs() > 1e-3).eq((delta.abs() > 1e-3)).float().mean().item() > 0.999
 

@@ -99,12 +99,13 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _hip.lib().stonk_abi_version() == 1
+    assert _hip.lib().stonk_abi_version() == 2
 
 
 def test_bad_arguments_are_rejected_without_touching_the_gpu():
     lib = _hip.lib()
-    assert lib.stonk_gemm_nt_bf16(0, 0, 0, 0, 0, 0, 1, 128, 64, 0, 0, 0, 0, 0, 0, 1.0, 1, 0, 0, 0.0, 0, 0) == -1
+    assert lib.stonk_gemm_nt_bf16(0, 0, 0, 0, 0, 0, 1, 128, 64, 0, 0, 0, 0, 0, 0, 1.0, 1, 0, 0, 0.0, 0, 0, 0) == -1
+    assert lib.stonk_gemm_nt_bf16(16, 64, 16, 64, 16, 128, 1, 128, 64, 0, 0, 0, 0, 0, 0, 1.0, 1, 0, 0, 0.0, 0, 9, 0) == -1   # unknown kernel
     assert lib.stonk_layernorm_fwd(16, 16, 16, 16, 0, 0, 4, 7, 1e-12, 0, 0.0, 0, 0) == -2
     assert lib.stonk_attention_fwd(16, 16, 16, 192, 0, 16, 64, 0, 1, 1, 100, 64, 0.125, 0.0, 0, 0) == -2
     with pytest.raises(_hip.StonkHipError):

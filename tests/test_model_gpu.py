@@ -54,11 +54,12 @@ def test_forward_matches_reference_golden(g2):
     # quirk Q2: LM special-token rows of the entity table
     for sid in (100, 102, 103):
         assert _rel(model.kg_backbone[sid], gold[f"special_{sid}"]) < 2e-2
-    # loss: |delta| <= 2e-2 absolute on ~12.7 (bf16 activations); terms individually
-    assert abs(float(out.loss) - float(gold["loss"])) < 2e-2
+    # loss: |delta| < 1e-2 absolute on ~12.7 (bf16 activations; measured 1-5e-3 - DESIGN section 2 relates this to
+    # north_star's 1e-3); terms individually
+    assert abs(float(out.loss) - float(gold["loss"])) < 1e-2
     terms = [float(t) for t in model.last_loss_terms]
     for got, key in zip(terms, ("masked_lm_loss", "ent_masked_lm_loss", "next_sentence_loss")):
-        assert abs(got - float(gold[key])) < 2e-2, key
+        assert abs(got - float(gold[key])) < 1e-2, key
     assert _rel(out.pooler_output, gold["pooler_output"]) < 2e-2
     assert _rel(out.seq_relationship_logits, gold["nsp_logits"]) < 3e-2
     assert _rel(out.hidden_states[:, ::7, ::3], gold["hidden_states_s"]) < 2e-2
@@ -77,7 +78,7 @@ def test_backward_matches_reference_golden(g2):
     model.train()
     model.zero_grad()      # zeroes the flat gradient buffer the engine accumulates into
     loss = model(**batch)[0]
-    assert abs(float(loss) - float(gold["loss"])) < 2e-2
+    assert abs(float(loss) - float(gold["loss"])) < 1e-2
     loss.backward()
     grads = dict(model.named_parameters())
     total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.requires_grad))
@@ -99,7 +100,7 @@ def test_two_optimizer_steps_match_reference_golden(hip):
     model = _build(cfg, sd, tsv_rows)
     tr = Trainer(model, TrainingArguments(max_steps=200, learning_rate=1e-4, per_device_train_batch_size=3))
     losses = [float(tr.training_step(model, batch)) for _ in range(2)]
-    np.testing.assert_allclose(losses, gold["step_losses"], atol=2e-2)
+    np.testing.assert_allclose(losses, gold["step_losses"], atol=1e-2)
     params = dict(model.named_parameters())
     for k in meta["grad_keys"]:
         before = sd[k]
@@ -154,7 +155,7 @@ def test_against_oracle_on_fresh_batch_and_masks(g2):
     model.train()
     model.zero_grad()
     loss = model.forward_backward(b)
-    assert abs(float(loss) - float(res["loss"])) < 2e-2
+    assert abs(float(loss) - float(res["loss"])) < 1e-2
     gv = model.named_grad_views()
     for k in meta["grad_keys"]:
         e = _rel(gv[k], res["grads"][k])
@@ -186,7 +187,7 @@ def test_dropout_training_mode_is_statistically_consistent(hip):
     model.eval()
     with torch.no_grad():
         le = float(model(**batch)[0])
-    assert abs(le - float(gold["loss"])) < 2e-2  # eval mode switches every dropout off
+    assert abs(le - float(gold["loss"])) < 1e-2  # eval mode switches every dropout off
 
 
 def test_checkpoint_resume_continues_the_uninterrupted_run(hip, tmp_path):

@@ -178,3 +178,37 @@ def test_config1_example_batch_at_12_layers(hip):
     tl, el = out.prediction_logits
     assert _rel(tl, ref["text_logits"]) < 3e-2 and _rel(el, ref["ent_logits"]) < 3e-2
     assert _rel(out.seq_relationship_logits, ref["nsp_logits"]) < 3e-2
+
+
+def test_config4_24_layers_1024_wide(hip):
+    """BASELINE.json configs[3] at its real depth and width: 24L / 1024h / 16 heads / 4096 FFN (frozen backbone and entity
+    table at width 1024 too - a synthetic scale-up, the reference only builds 12L / 768), small
+    vocabularies and S = 256 so that the oracle finishes in seconds: loss terms, global gradient norm, EVERY gradient tensor."""
+    from stonkgs_amd.data import synthetic_batch
+
+    cfg = orc.OracleConfig(vocab_size=2048, kg_vocab_size=640, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                           intermediate_size=4096, max_position_embeddings=256)
+    sd = orc.init_state_dict(cfg, seed=41)
+    g = torch.Generator().manual_seed(42)
+    tsv_rows = torch.randn(cfg.kg_vocab_size, cfg.hidden_size, generator=g, dtype=torch.float64) * 0.3
+    batch = synthetic_batch(2, cfg.vocab_size, cfg.kg_vocab_size, 256, seed=43, min_text=16)
+    model = _build(cfg, sd, tsv_rows)
+    model.train()
+    model.zero_grad()
+    loss = model.forward_backward(batch)
+    model.engine.check_errors()
+    with torch.no_grad():
+        table = orc.build_kg_table(tsv_rows, orc.special_vectors(sd, cfg))
+    ref = orc.train_step(sd, cfg, table, batch, orc.AdamState(), max_grad_norm=0.0, base_lr=0.0)
+    terms = [float(t) for t in model.last_loss_terms]
+    d = [abs(float(loss) - float(ref["loss"]))] + [abs(t - float(ref[k])) for t, k in
+                                                   zip(terms, ("masked_lm_loss", "ent_masked_lm_loss", "next_sentence_loss"))]
+    print("config 4 (24L/1024h): |dloss|, |dterms| =", ["%.2e" % x for x in d])
+    assert max(d) < 1.5e-2          # 24 layers of bf16 activations; measured ~5e-3 on a loss of ~15
+    gv = model.named_grad_views()
+    tot = torch.sqrt(sum((v.double() ** 2).sum() for v in gv.values()))
+    assert abs(float(tot) - float(ref["grad_norm"])) < 3e-2 * float(ref["grad_norm"])
+    errs = {k: _rel(gv[k], ref["grads"][k]) for k in ref["grads"]}
+    worst = max(errs.items(), key=lambda t: t[1])
+    print("config 4 worst gradient tensor:", worst)
+    assert worst[1] < 8e-2, worst    # (the deepest layers' gradients pass through 24 layers of bf16 rounding)

@@ -29,7 +29,7 @@ torch.cuda.synchronize()
 res = {True: [], False: []}
 for rnd in range(6):
     for val in (True, False):
-        if attr.startswith("env:"):   # a library switch read per call with getenv: True = variable set
+        if attr.startswith("env:"):   # an environment switch read by the process under test: True = variable set
             name, _, value = attr[4:].partition("=")   # env:NAME or env:NAME=VALUE
             if val:
                 os.environ[name] = value or "1"
@@ -37,6 +37,8 @@ for rnd in range(6):
                 os.environ.pop(name, None)
         elif attr.startswith("args:"):   # a TrainingArguments switch
             setattr(tr.args, attr[5:], val)
+        elif attr.startswith("kernel:"):   # kernel:SITE=K[,SITE=K]: pin NT kernels (Engine.kernel_for) against the library's choice
+            model.engine.kernel_for = ({k: int(v) for k, v in (kv.split("=") for kv in attr[7:].split(","))} if val else {})
         else:
             setattr(model.engine, attr, val)
         torch.cuda.synchronize()

@@ -18,13 +18,13 @@ B = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
 C = torch.zeros(cap, N, device="cuda")
 cnt = torch.tensor([cnt_v], device="cuda", dtype=torch.int32)
 ref = None
-for name, dbg, sks in (("128x128", hip.EPI_DEBUG_V1, (16, 32)), ("256x256 eight-wave", hip.EPI_DEBUG_V2, (4, 8, 9, 12)),
-                       ("256x256 four-wave", hip.EPI_DEBUG_W4, (8, 9))):
+for name, dbg, sks in (("128x128", hip.GEMM_TILE128, (16, 32)), ("256x256 eight-wave", hip.GEMM_WAVE8, (4, 8, 9, 12)),
+                       ("256x256 four-wave", hip.GEMM_WAVE4, (8, 9))):
     for sk in sks:
         def f():
             return hip.lib().stonk_gemm_nt_bf16(hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, cap, N, K,
-                                                hip.EPI_OUT_F32_ATOMIC | dbg, 0, 0, 0, 0, 0, 1.0, sk, hip.ptr(cnt), 0, 0.0, 0,
-                                                hip.stream_ptr())
+                                                hip.EPI_OUT_F32_ATOMIC, 0, 0, 0, 0, 0, 1.0, sk, hip.ptr(cnt), 0, 0.0, 0,
+                                                dbg, hip.stream_ptr())
         rc = f()
         if rc != 0:
             print(f"{name} split {sk}: refused ({rc})", flush=True)

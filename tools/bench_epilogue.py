@@ -22,10 +22,10 @@ for M, N, K in [(32768, 3072, 768), (32768, 2304, 768), (16384, 3072, 768), (327
              "bias+gelu+save'": hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT | hip.EPI_AUX_GRAD,
              "gelu_bwd": hip.EPI_GELU_BWD, "mul_aux": hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD, "bias+resid": hip.EPI_BIAS | hip.EPI_RESID,
              "bias+drop+resid": hip.EPI_BIAS | hip.EPI_RESID | hip.EPI_DROPOUT}
-    for kname, dbg in (("v1", hip.EPI_DEBUG_V1), ("v2", hip.EPI_DEBUG_V2), ("w4", hip.EPI_DEBUG_W4)):
+    for kname, dbg in (("v1", hip.GEMM_TILE128), ("v2", hip.GEMM_WAVE8), ("w4", hip.GEMM_WAVE4)):
         for cname, fl in cases.items():
             def f():
-                hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, M, N, K, fl | dbg,
-                         hip.ptr(bias), hip.ptr(res), N, hip.ptr(aux), N, 1.0, 1, 0, 0, 0.1, 7, hip.stream_ptr())
+                hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, M, N, K, fl,
+                         hip.ptr(bias), hip.ptr(res), N, hip.ptr(aux), N, 1.0, 1, 0, 0, 0.1, 7, dbg, hip.stream_ptr())
             t = timeit(f, iters=10)
             print(f"{M}x{N}x{K} {kname} {cname}: {t*1e6:.1f} us  {2*M*N*K/t/1e12:.0f} TF/s", flush=True)

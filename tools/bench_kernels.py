@@ -29,27 +29,27 @@ def bench_gemm():
         A = (torch.randn(M, K, device="cuda")).to(torch.bfloat16)
         B = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
         C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-        for name, dbg in (("v1_128", hip.EPI_DEBUG_V1), ("v2_256", hip.EPI_DEBUG_V2), ("w4_256", hip.EPI_DEBUG_W4)):
+        for name, dbg in (("v1_128", hip.GEMM_TILE128), ("v2_256", hip.GEMM_WAVE8), ("w4_256", hip.GEMM_WAVE4)):
             def f():
-                hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, M, N, K, dbg, 0, 0, 0, 0, 0,
-                         1.0, 1, 0, 0, 0.0, 0, hip.stream_ptr())
+                hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, M, N, K, 0, 0, 0, 0, 0, 0,
+                         1.0, 1, 0, 0, 0.0, 0, dbg, hip.stream_ptr())
             t = timeit(f)
             print(f"gemm {M}x{N}x{K} {name}: {t*1e6:.1f} us  {2*M*N*K/t/1e12:.1f} TF/s", flush=True)
         t = timeit(lambda: torch.matmul(A, B.t()))
         print(f"gemm {M}x{N}x{K} torch(hipBLASLt): {t*1e6:.1f} us  {2*M*N*K/t/1e12:.1f} TF/s", flush=True)
     # wgrad-shaped: small output, long K, split-K atomics
-    for Mo, No, K, sk, dbg in [(768, 768, 32768, 16, hip.EPI_DEBUG_V1), (768, 768, 32768, 28, hip.EPI_DEBUG_V2),
-                               (3072, 768, 32768, 5, hip.EPI_DEBUG_V1), (3072, 768, 32768, 7, hip.EPI_DEBUG_V2),
-                               (3072, 768, 32768, 14, hip.EPI_DEBUG_V2), (2304, 768, 32768, 6, hip.EPI_DEBUG_V1),
-                               (2304, 768, 32768, 9, hip.EPI_DEBUG_V2), (2304, 768, 32768, 19, hip.EPI_DEBUG_V2)]:
+    for Mo, No, K, sk, dbg in [(768, 768, 32768, 16, hip.GEMM_TILE128), (768, 768, 32768, 28, hip.GEMM_WAVE8),
+                               (3072, 768, 32768, 5, hip.GEMM_TILE128), (3072, 768, 32768, 7, hip.GEMM_WAVE8),
+                               (3072, 768, 32768, 14, hip.GEMM_WAVE8), (2304, 768, 32768, 6, hip.GEMM_TILE128),
+                               (2304, 768, 32768, 9, hip.GEMM_WAVE8), (2304, 768, 32768, 19, hip.GEMM_WAVE8)]:
         A = torch.randn(Mo, K, device="cuda").to(torch.bfloat16)
         B = torch.randn(No, K, device="cuda").to(torch.bfloat16)
         C = torch.zeros(Mo, No, device="cuda")
         def f():
             hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), No, Mo, No, K,
-                     hip.EPI_OUT_F32_ATOMIC | dbg, 0, 0, 0, 0, 0, 1.0, sk, 0, 0, 0.0, 0, hip.stream_ptr())
+                     hip.EPI_OUT_F32_ATOMIC, 0, 0, 0, 0, 0, 1.0, sk, 0, 0, 0.0, 0, dbg, hip.stream_ptr())
         t = timeit(f)
-        print(f"wgrad {Mo}x{No}x{K} splitk={sk} {'v2' if dbg == hip.EPI_DEBUG_V2 else 'v1'}: {t*1e6:.1f} us  "
+        print(f"wgrad {Mo}x{No}x{K} splitk={sk} {'v2' if dbg == hip.GEMM_WAVE8 else 'v1'}: {t*1e6:.1f} us  "
               f"{2*Mo*No*K/t/1e12:.1f} TF/s", flush=True)
 
 

@@ -8,6 +8,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stonkgs_amd import _hip as hip  # noqa: E402
 from stonkgs_amd.config import STonKGsConfig  # noqa: E402
 from stonkgs_amd.data import synthetic_batch  # noqa: E402
 from stonkgs_amd.stonkgs_model import STonKGsForPreTraining  # noqa: E402
@@ -24,7 +25,7 @@ torch.cuda.synchronize()
 res = {True: [], False: []}
 for rnd in range(6):
     for val in (True, False):
-        model.engine.fwd_w4 = val
+        model.engine.kernel_for = {"qkv": hip.GEMM_WAVE4, "ffn_up": hip.GEMM_WAVE4} if val else {}
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(10):

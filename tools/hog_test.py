@@ -36,8 +36,8 @@ def wgrad(sk):
 
 
 def nt(dbg):
-    hip.call("stonk_gemm_nt_bf16", hip.ptr(X), 768, hip.ptr(W), 768, hip.ptr(C), 3072, T, 3072, 768, dbg, 0, 0, 0, 0, 0, 1.0, 1,
-             0, 0, 0.0, 0, hip.stream_ptr())
+    hip.call("stonk_gemm_nt_bf16", hip.ptr(X), 768, hip.ptr(W), 768, hip.ptr(C), 3072, T, 3072, 768, 0, 0, 0, 0, 0, 0, 1.0, 1,
+             0, 0, 0.0, 0, dbg, hip.stream_ptr())
 
 
 def timed(fn, with_hog, n_hog=32, usec=500):
@@ -62,8 +62,8 @@ def timed(fn, with_hog, n_hog=32, usec=500):
 for name, fn in (("weight gradient, four-wave 256x256, all CUs", lambda: wgrad(0)),
                  ("weight gradient, four-wave 256x256, 160 CUs", lambda: wgrad(-160)),
                  ("weight gradient, 128x128 split 12", lambda: wgrad(12)),
-                 ("NT 32768x3072x768, persistent 256x256", lambda: nt(hip.EPI_DEBUG_V2)),
-                 ("NT 32768x3072x768, 128x128", lambda: nt(hip.EPI_DEBUG_V1))):
+                 ("NT 32768x3072x768, persistent 256x256", lambda: nt(hip.GEMM_WAVE8)),
+                 ("NT 32768x3072x768, 128x128", lambda: nt(hip.GEMM_TILE128))):
     for _ in range(2):
         fn()
     a = timed(fn, False)

@@ -17,6 +17,6 @@ res = torch.randn(M, N, device="cuda").to(torch.bfloat16)
 bias = torch.randn(N, device="cuda")
 for fl in (0, hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT, hip.EPI_GELU_BWD, hip.EPI_BIAS | hip.EPI_RESID):
     for _ in range(3):
-        hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, M, N, K, fl | hip.EPI_DEBUG_V2,
-                 hip.ptr(bias), hip.ptr(res), N, hip.ptr(aux), N, 1.0, 1, 0, 0, 0.1, 7, hip.stream_ptr())
+        hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, M, N, K, fl,
+                 hip.ptr(bias), hip.ptr(res), N, hip.ptr(aux), N, 1.0, 1, 0, 0, 0.1, 7, hip.GEMM_WAVE8, hip.stream_ptr())
     torch.cuda.synchronize()

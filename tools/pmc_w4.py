@@ -13,10 +13,9 @@ A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
 B = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
 C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 for _ in range(3):
-    hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, M, N, K, hip.EPI_DEBUG_W4, 0, 0, 0, 0, 0,
-             1.0, 1, 0, 0, 0.0, 0, hip.stream_ptr())
+    hip.call("stonk_gemm_nt_bf16", hip.ptr(A), K, hip.ptr(B), K, hip.ptr(C), N, M, N, K, 0, 0, 0, 0, 0, 0,
+             1.0, 1, 0, 0, 0.0, 0, hip.GEMM_WAVE4, hip.stream_ptr())
 torch.cuda.synchronize()
-if os.environ.get("STONK_W4_VAR", "0") == "0":
-    for _ in range(3):
-        torch.matmul(A, B.t())
-    torch.cuda.synchronize()
+for _ in range(3):
+    torch.matmul(A, B.t())
+torch.cuda.synchronize()

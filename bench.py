@@ -41,7 +41,7 @@ GFLOP_PER_PAIR_STEP = 373.4
 # build BioBERT's 12L/768; frozen backbone and node2vec table are instantiated at width 1024)
 MODELS = {
     "150k": dict(batch=64, cfg={}, name="STonKGs-150k pretraining step (12L/768h, V=28996, K=175094)"),
-    "24L1024": dict(batch=32, cfg=dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+    "24L1024": dict(batch=64, cfg=dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
                                        intermediate_size=4096),
                     name="STonKGs 24L/1024h synthetic scale-up pretraining step (V=28996, K=175094, frozen backbone and "
                          "table at width 1024)"),
@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (BASELINE config 2: 64; 24L1024: 32)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 64, BASELINE config 2)")
     ap.add_argument("--model", choices=sorted(MODELS), default="150k",
                     help="150k = BASELINE config 2/3 (12L/768h, the headline); 24L1024 = config 4 (synthetic scale-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

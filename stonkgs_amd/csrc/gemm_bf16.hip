@@ -21,7 +21,7 @@ using namespace stonk_gemm;
 
 // defined in gemm256.hip
 int stonk_gemm256_launch(const GemmArgs& a, int out_mode, hipStream_t st);
-int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, hipStream_t st);
+int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, int tile_n, hipStream_t st);
 
 namespace {
 
@@ -302,7 +302,7 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
                                   const int* m_dev, const int* k_dev, float drop_p, uint32_t seed, int kernel,
                                   void* stream) {
   STONK_CHECK_ARG(A && B && C, STONK_EINVAL);
-  STONK_CHECK_ARG(kernel >= STONK_GEMM_AUTO && kernel <= STONK_GEMM_WAVE4, STONK_EINVAL);
+  STONK_CHECK_ARG(kernel >= STONK_GEMM_AUTO && kernel <= STONK_GEMM_WAVE4_192, STONK_EINVAL);
   STONK_CHECK_ARG(M >= 0 && N > 0 && K > 0, STONK_ESHAPE);
   STONK_CHECK_ARG(N % BN == 0 && K % BK == 0, STONK_ESHAPE);
   STONK_CHECK_ARG(split_k >= 1 && split_k <= K / BK, STONK_ESHAPE);
@@ -355,7 +355,8 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   //  * launches whose epilogue reads a second [M,N] operand (residual, saved GELU') go to the four-wave kernel: its
   //    128x128 wave tiles halve the LDS bytes per flop and its epilogue requests the side operand a round ahead
   //    (FFN-down / attention-output forward 157 against 174 us, dgrad + residual 152 against 177, dgrad through GELU' 172
-  //    against 200; -1.4 ms per step together);
+  //    against 200; -1.4 ms per step together) - on 256x192 tiles where those quantise better (N = 768: two full rounds
+  //    of the CUs instead of one and a half; another 8-21 % per launch);
   //  * wide plain launches (fused QKV, FFN-up, the label-sparse decoders) stay on the eight-wave kernel: the four-wave one
   //    is faster per launch there too (105 against 125 us) but draws more power, every other kernel of the step slows by
   //    1-4 % and the step does not get shorter;
@@ -365,10 +366,14 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   if (k == STONK_GEMM_AUTO)
     k = (w4_ok && w4_side && M >= 1024 && out_mode == STONK_EPI_OUT_BF16) ? STONK_GEMM_WAVE4
         : (v2_ok && big)                                                     ? STONK_GEMM_WAVE8
+        // ... and the plain N = 768 launches (attention-output dgrad, the head transform's dgrad) since the four-wave kernel
+        // has 256x192 tiles: 42.6 against 52.3 us (tools/bench_w4_tiles.py)
+        : (w4_ok && M >= 1024 && N % 192 == 0 && out_mode == STONK_EPI_OUT_BF16 && (flags & 0x1FC) == 0) ? STONK_GEMM_WAVE4
                                                                              : STONK_GEMM_TILE128;
-  if (k == STONK_GEMM_WAVE4) {
+  if (k == STONK_GEMM_WAVE4 || k == STONK_GEMM_WAVE4_192) {
     STONK_CHECK_ARG(w4_ok, STONK_ESHAPE);
-    return stonk_gemm_w4_launch(a, out_mode, st);
+    // chosen by AUTO: the launcher also picks the tile width (256x192 where N = 768 / 2304 quantise better on 256 CUs)
+    return stonk_gemm_w4_launch(a, out_mode, kernel == STONK_GEMM_AUTO ? 0 : (k == STONK_GEMM_WAVE4 ? 256 : 192), st);
   }
   if (k == STONK_GEMM_WAVE8) {
     STONK_CHECK_ARG(v2_ok, STONK_ESHAPE);

@@ -34,7 +34,7 @@ using namespace stonk_gemm;
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int BM = 256, BK = 64;   // the tile is BM x BN_ with BN_ = 256 or 192 (template parameter)
 constexpr int IMG_BYTES = 256 * BK * 2;             // one operand of one K tile: 32 KiB
 constexpr int STAGE_BYTES = 2 * IMG_BYTES;          // 64 KiB
 constexpr int LDS_RING = 2 * STAGE_BYTES;           // 128 KiB
@@ -59,8 +59,17 @@ __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0
 
 // VAR: timing experiments only (bit 0 no barrier, bit 2 no global loads / LDS writes in the loop, bit 3 no fragment
 // reads in the loop, bit 4 loads but no LDS writes, bit 5 LDS writes but no loads) - anything but 0 computes garbage.
-template <int OUT_MODE, int EPI, int VAR = 0>
+// BN_ = 192 (128x96 wave tiles, 4 x 3 MFMA blocks): N = 768 = 4 x 192 tiles the 32 768-row outputs of the step into 512
+// work items = two full rounds of the 256 CUs, where 3 x 256 gives 384 = one and a half (the second round half empty: 75 %
+// tile efficiency); 16 384 rows (frozen backbone) give 256 items = one full round instead of 192. The B image shrinks to
+// 192 rows (six 1-KiB pieces per wave and K tile instead of eight), everything else keeps its place.
+template <int OUT_MODE, int EPI, int BN_ = 256, int VAR = 0>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
+  static_assert(BN_ == 256 || BN_ == 192, "tile widths: 256 or 192");
+  constexpr int BN = BN_;
+  constexpr int NB = BN_ / 64;        // 32-column blocks per wave
+  constexpr int BROWS_W = BN_ / 4;    // rows of the B image each wave stages
+  constexpr int NPB = BROWS_W / 8;    // ... in this many 8-row pieces per K tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -126,8 +135,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     const int c0 = ((lane & 7) ^ (l8 >> 1)) * 16;
     voffA[0] = (wave * 64 + l8) * lda2 + c0;
     voffA[1] = (wave * 64 + l8) * lda2 + (c0 ^ 64);
-    voffB[0] = (wave * 64 + l8) * ldb2 + c0;
-    voffB[1] = (wave * 64 + l8) * ldb2 + (c0 ^ 64);
+    voffB[0] = (wave * BROWS_W + l8) * ldb2 + c0;   // (BROWS_W % 16 == 0: the image rows' swizzle period)
+    voffB[1] = (wave * BROWS_W + l8) * ldb2 + (c0 ^ 64);
   }
   const int pstepA = 8 * lda2, pstepB = 8 * ldb2;   // byte distance between consecutive pieces (uniform)
   // (An inline-asm variant of these loads, whose waits are all hand-counted, removes the compiler's conservative wait
@@ -135,7 +144,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   // compiler then spills in-flight staging registers around the epilogue: not shippable. See DESIGN.md section 4.2.)
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.M * lda2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, N * ldb2, 0x00020000);
-  const int wofs = wave * 8192 + lane * 16;   // this lane's 16 bytes of piece 0 of this wave inside an operand image
+  const int wofs = wave * 8192 + lane * 16;   // this lane's 16 bytes of piece 0 of this wave inside the A image
+  const int wofsB = wave * (BROWS_W * 128) + lane * 16;   // ... inside the B image
   int soffA = 0, soffB = 0;   // scalar byte offsets of the K tile the prefetch cursor points at
   auto set_sources = [&](const Work& w) {
     soffA = w.m0 * lda2 + (int)w.k_begin * 2;
@@ -143,13 +153,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   };
   // piece q of this wave: q < 8 -> A rows 64 wave + 8 q .., q >= 8 -> B rows 64 wave + 8 (q - 8) ..
   auto load_piece = [&](const int q, bf16x8& d) {
+    if (q >= 8 + NPB) return;   // (BN_ = 192: the B image has six pieces per wave; q is a compile-time constant at every use)
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     const u32x4 v = (q < 8) ? __builtin_amdgcn_raw_buffer_load_b128(rsrcA, voffA[q & 1], soffA + (q & 7) * pstepA, 0)
                             : __builtin_amdgcn_raw_buffer_load_b128(rsrcB, voffB[q & 1], soffB + (q & 7) * pstepB, 0);
     d = __builtin_bit_cast(bf16x8, v);
   };
   auto write_piece = [&](const int stage, const int q, const bf16x8& d) {
-    *(bf16x8*)(smem + stage * IMG_BYTES + (q < 8 ? 0 : 2 * IMG_BYTES) + (q & 7) * 1024 + wofs) = d;
+    if (q >= 8 + NPB) return;
+    *(bf16x8*)(smem + stage * IMG_BYTES + (q < 8 ? wofs : 2 * IMG_BYTES + wofsB) + (q & 7) * 1024) = d;
   };
   bf16x8 stg[4][4];   // [k step][piece]: loaded in k step ks of one K tile, written in k step ks of the next
 
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   for (int ks = 0; ks < 4; ++ks) {
     const int o = r * 128 + (((2 * ks + hh) ^ ((r >> 1) & 7)) << 4);
     lofsA[ks] = o + wr * 16384;               // this wave's 128 rows of the A image
-    lofsB[ks] = o + wc * 16384 + 2 * IMG_BYTES;   // ... and of the B image (A images at 0 / 32 KiB, B at 64 / 96 KiB:
+    lofsB[ks] = o + wc * (BN_ / 2) * 128 + 2 * IMG_BYTES;   // ... and of the B image (A images at 0 / 32 KiB, B at 64 / 96 KiB:
                                                   // either stage is within a 16-bit immediate of these two bases)
   }
   bf16x8 fr[2][8];   // [set][0-3: A row blocks, 4-7: B column blocks]
@@ -169,11 +181,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       f[b] = *(const bf16x8*)(s + b * 4096 + lofsA[ks]);
-      f[4 + b] = *(const bf16x8*)(s + b * 4096 + lofsB[ks]);
+      if (b < NB) f[4 + b] = *(const bf16x8*)(s + b * 4096 + lofsB[ks]);
     }
   };
 
-  f32x16 acc[4][4];   // [32-row block][32-column block]
+  f32x16 acc[4][NB];   // [32-row block][32-column block]
   f32x16 fzero;   // first k step of a work item: C = 0 as the MFMA's inline constant (no 256-register clear)
 #pragma unroll
   for (int e = 0; e < 16; ++e) fzero[e] = 0.f;
@@ -220,7 +232,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   // epilogue vm operations that can still be outstanding during the four k steps after a tile boundary
   constexpr int FL = EPI >= 0 ? EPI : 0;
   constexpr int S = (OUT_MODE == 0) ? ((FL & STONK_EPI_SAVE_PREACT) || EPI < 0 ? 64 : 32) : (OUT_MODE == 1 ? 64 : 0);
-  constexpr int WAIT_POST = (12 + S) > 63 ? 63 : (12 + S);
+  // loads that stay in flight behind the wait of k step KS: the pieces requested by the three other k steps of a K tile
+  // (16 pieces, four per k step, at BN_ = 256; 14 - k step 2 requests only two - at 192)
+  constexpr int NLOADS = 8 + NPB;
+#define STONK_W4_LOADS_OF(KS) ((4 * (((KS) + 1) & 3) + 4 <= NLOADS) ? 4 : (NLOADS - 4 * (((KS) + 1) & 3) > 0 ? NLOADS - 4 * (((KS) + 1) & 3) : 0))
 
   // One k step. ST = stage of the K tile being multiplied, KS = k step. Pieces written here: 4 ((KS + 1) & 3) .. +3 of
   // K tile t+1 (KS = 3: of t+2), into the stage not being multiplied... which for KS = 3 IS stage ST: safe, every wave
@@ -231,9 +246,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     constexpr int Q0 = 4 * (((KS) + 1) & 3);                                                           \
     constexpr int RST = ((KS) == 3) ? ((ST) ^ 1) : (ST);                                               \
     constexpr int RKS = ((KS) + 1) & 3;                                                                \
+    constexpr int WAIT = NLOADS - STONK_W4_LOADS_OF(KS);                                               \
+    constexpr int WAIT_POST = (WAIT + S) > 63 ? 63 : (WAIT + S);                                       \
     if (!(VAR & 4) && !(VAR & 16)) {                                                                   \
       if (post) wait_vm<WAIT_POST>();                                                                  \
-      else wait_vm<12>();                                                                              \
+      else wait_vm<WAIT>();                                                                            \
     }                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                 \
     /* four sub-blocks of 4 MFMAs (one accumulator row) with ONE memory instruction per MFMA gap: the next k step's \
@@ -242,11 +259,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
       if (!(VAR & 8)) {                                                                                \
         fr[RKS & 1][g] = *(const bf16x8*)(smem + RST * IMG_BYTES + g * 4096 + lofsA[RKS]);             \
-        fr[RKS & 1][4 + g] = *(const bf16x8*)(smem + RST * IMG_BYTES + g * 4096 + lofsB[RKS]);         \
+        if (g < NB) fr[RKS & 1][4 + g] = *(const bf16x8*)(smem + RST * IMG_BYTES + g * 4096 + lofsB[RKS]); \
       }                                                                                                \
       if (!(VAR & 4) && !(VAR & 16)) write_piece(WST, Q0 + g, stg[KS][g]);                             \
       if (!(VAR & 4) && !(VAR & 32)) load_piece(Q0 + g, stg[KS][g]);                                   \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
+      _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                                 \
         /* swapped operands: D[n][m] - a lane holds one output row m and groups of 4 consecutive columns */ \
         acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(KS) & 1][4 + j], fr[(KS) & 1][g],        \
                                                             (FIRST) ? fzero : acc[g][j], 0, 0, 0);       \
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                               \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
       __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); /* DS write */                                \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                               \
+      if (NB == 4) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  /* (three MFMAs per sub-block at BN_ = 192) */ \
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); /* the buffer load (a VMEM read) */           \
       __builtin_amdgcn_sched_barrier(0);                                                               \
     }                                                                                                  \
@@ -334,7 +351,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, M * ldc_b, 0x00020000);
     const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, M * ldr_b, 0x00020000);
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.aux, 0, M * ldx_b, 0x00020000);
-    const int wm0 = w.m0 + (wv >> 1) * 128, wn0 = w.n0 + (wv & 1) * 128;
+    const int wm0 = w.m0 + (wv >> 1) * 128, wn0 = w.n0 + (wv & 1) * (BN_ / 2);
+    constexpr int WCOLS = BN_ / 2;   // columns of this wave's corner: the second 64-column round is half empty at BN_ = 192
     // Side operand (residual OR saved GELU input / GELU', never both here): the four 16-byte pieces a lane needs in round
     // k + 1 are requested as soon as round k has consumed its own - requested at their point of use, every round paid a full
     // memory latency (a 50 MB residual cost 35 us where its HBM time is 10). 16 registers, reused round after round
@@ -347,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
       if (!SIDE) return;
       const int bi2 = round >> 1, qb2 = round & 1;
       const int mrow0 = wm0 + bi2 * 32, n0 = wn0 + qb2 * 64;
-      const int oob = (n0 + c8 * 8 < N) ? 0 : 0x40000000;
+      const int oob = (n0 + c8 * 8 < N && qb2 * 64 + c8 * 8 < WCOLS) ? 0 : 0x40000000;
       const int vo = rrow * (SIDE_X ? ldx_b : ldr_b) + c8 * 16 + oob;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -365,14 +383,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
         const int mrow0 = wm0 + bi * 32;
         const int n0 = wn0 + qb * 64;
         const int n = n0 + c8 * 8;
-        const bool n_ok = n < N;
-        const int oob = n_ok ? 0 : 0x40000000;   // columns past N: pushed out of the buffer's range
+        const bool n_ok = n < N && qb * 64 + c8 * 8 < WCOLS;
+        const int oob = n_ok ? 0 : 0x40000000;   // columns past N (or past this wave's corner): pushed out of the buffer's range
         const f32x4 b0 = bq[qb][0], b1 = bq[qb][1];
         // write: lane holds row r, register group g -> columns 8g + 4hh .. +3 of each 32-column block
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
+            if (2 * qb + bj >= NB) continue;      // (BN_ = 192: no fourth column block; its slab columns are never stored)
             const int ch = bj * 8 + 2 * g + hh;   // 16-byte chunk of the 256-byte slab row
             const f32x16& c = acc[bi][2 * qb + bj];
             f32x4 v = {c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
@@ -384,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
 #pragma unroll 4
           for (int rr = 0; rr < 32; ++rr) {
             const float x = *(const float*)(ep + rr * 256 + (((lv >> 2) ^ (rr & 15)) << 4) + (lv & 3) * 4);
-            if (mrow0 + rr < M && n0 + lv < N) atomicAdd((float*)p.C + (long)(mrow0 + rr) * p.ldc + n0 + lv, x);
+            if (mrow0 + rr < M && n0 + lv < N && qb * 64 + lv < WCOLS) atomicAdd((float*)p.C + (long)(mrow0 + rr) * p.ldc + n0 + lv, x);
           }
         } else {
           const int voC = rrow * ldc_b + c8 * 8 * esz + oob;
@@ -454,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int n = cw.n0 + wc * 128 + qb * 64 + (lv & 7) * 8 + h * 4;
+          const int n = cw.n0 + wc * (BN_ / 2) + qb * 64 + (lv & 7) * 8 + h * 4;
           bq[qb][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBias, n * 4, 0, 0));
         }
     }
@@ -487,25 +506,26 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
   wait_vm<0>();   // (the cursor's last, unused loads)
 #undef STONK_W4_KTILE
 #undef STONK_W4_KSTEP
+#undef STONK_W4_LOADS_OF
 }
 
-template <int OUT_MODE, int EPI, int VAR = 0>
+template <int OUT_MODE, int EPI, int BN_ = 256>
 int launch_w4(const GemmArgs& a, int grid, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<OUT_MODE, EPI, VAR>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<OUT_MODE, EPI, BN_>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS_BYTES);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_w4_kernel<OUT_MODE, EPI, VAR>), dim3(grid), dim3(256), LDS_BYTES, st, a);
+  hipLaunchKernelGGL((gemm_w4_kernel<OUT_MODE, EPI, BN_>), dim3(grid), dim3(256), LDS_BYTES, st, a);
   return stonk_launch_status();
 }
 
 }  // namespace
 
 // Launcher used by stonk_gemm_nt_bf16 (gemm_bf16.hip). Requires K % 64 == 0 and an EVEN number of K tiles per work item
-// (the K loop is unrolled by two; every GEMM of the STonKGs step has K = 768, 2304 or 3072).
-int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, hipStream_t st) {
+// (the K loop is unrolled by two; every GEMM of the STonKGs step has K = 768, 2304 or 3072). tile_n: 0 = choose, 256, 192.
+int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, int tile_n, hipStream_t st) {
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -513,11 +533,32 @@ int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
     n_cu = prop.multiProcessorCount;
   }
-  const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.split_k;
-  const int grid = (int)(tiles < n_cu ? tiles : n_cu);
   constexpr int B = STONK_EPI_BIAS, G = STONK_EPI_GELU, SV = STONK_EPI_SAVE_PREACT, GB = STONK_EPI_GELU_BWD,
                 R = STONK_EPI_RESID, D = STONK_EPI_DROPOUT, AG = STONK_EPI_AUX_GRAD;
   const int epi = a.flags & (B | G | SV | GB | R | D | AG);
+  const long ntm = (a.M + BM - 1) / BM;
+  // 192-wide tiles where they quantise better: time ~ rounds of the CUs x tile width (the launches they are built for:
+  // N = 768 at 32 768 rows, two full rounds instead of one and a half; at 16 384 rows one full round instead of 3/4)
+  const bool has192 = out_mode == 0 && a.N % 192 == 0 && (epi == 0 || epi == B || epi == R || epi == (B | R) || epi == (B | R | D));
+  if (tile_n == 192 && !has192) return STONK_ESHAPE;
+  if (tile_n == 0) {
+    const long t256 = ntm * ((a.N + 255) / 256) * a.split_k, t192 = ntm * (a.N / 192) * a.split_k;
+    const long c256 = ((t256 + n_cu - 1) / n_cu) * 256, c192 = ((t192 + n_cu - 1) / n_cu) * 192;
+    tile_n = (has192 && c192 < c256) ? 192 : 256;
+  }
+  if (tile_n == 192) {
+    const long tiles = ntm * (a.N / 192) * a.split_k;
+    const int grid = (int)(tiles < n_cu ? tiles : n_cu);
+    switch (epi) {
+      case 0: return launch_w4<0, 0, 192>(a, grid, st);
+      case B: return launch_w4<0, B, 192>(a, grid, st);
+      case R: return launch_w4<0, R, 192>(a, grid, st);
+      case B | R: return launch_w4<0, B | R, 192>(a, grid, st);
+      default: return launch_w4<0, B | R | D, 192>(a, grid, st);
+    }
+  }
+  const long tiles = ntm * ((a.N + 255) / 256) * a.split_k;
+  const int grid = (int)(tiles < n_cu ? tiles : n_cu);
   if (out_mode == 1) return epi == 0 ? launch_w4<1, 0>(a, grid, st) : launch_w4<1, -1>(a, grid, st);
   if (out_mode == 2) return launch_w4<2, 0>(a, grid, st);
   switch (epi) {   // the combinations the STonKGs step uses are compiled with constant flags

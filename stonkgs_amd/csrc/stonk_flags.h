@@ -23,6 +23,8 @@
                                  form to ask for when another stream (a collective) holds CUs during the launch */
 #define STONK_GEMM_WAVE8 2    /* persistent 256x256x64, eight waves, one workgroup per CU (gemm256.hip) */
 #define STONK_GEMM_WAVE4 3    /* persistent 256x256x64, four waves with 128x128 wave tiles (gemm_w4.hip) */
+#define STONK_GEMM_WAVE4_192 4 /* the same kernel on 256x192 tiles (128x96 wave tiles): N % 192 == 0, bf16 output, the \
+                                 epilogues of the N = 768 launches (none, bias, residual, bias + residual [+ dropout]) */
 // --- stonk_layernorm_* `flags` ---
 #define STONK_LN_DROPOUT (1 << 0)
 // --- stonk_small_linear_* `act` ---

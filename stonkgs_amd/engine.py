@@ -357,7 +357,8 @@ class Engine:
         self.wgrad(da, sv["ctx"], g_(prefix + ".attention.output.dense.weight"),
                    g_(prefix + ".attention.output.dense.bias"), H, H, T)
         dctx = self.buf("b.dctx", (T, H))
-        self.gemm(da, wt[prefix + ".attention.output.dense.weight"], dctx, T, H, H, kernel=self._kernel("dgrad_attn_out"))
+        self.gemm(da, wt[prefix + ".attention.output.dense.weight"], dctx, T, H, H,
+                  kernel=self._kernel("dgrad_attn_out", True))
         # ---- attention core
         qkv = sv["qkv"]
         dqkv = self.buf(f"b.dqkv.{par}", (T, 3 * H))
@@ -588,7 +589,7 @@ class Engine:
         self.wgrad(dut, sv["seq_out"], g_("cls.predictions.transform.dense.weight"),
                    g_("cls.predictions.transform.dense.bias"), H, H, T)
         dseq = self.buf("b.dseq", (T, H))
-        self.gemm(dut, wt["cls.predictions.transform.dense.weight"], dseq, T, H, H)
+        self.gemm(dut, wt["cls.predictions.transform.dense.weight"], dseq, T, H, H, kernel=self._kernel("dgrad_head", True))
         # ---- NSP + pooler (fp32), pooler gradient lands on position 0 of d(sequence_output)
         dnsp = sv["dnsp"]
         if gscale != 1.0:

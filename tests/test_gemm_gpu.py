@@ -312,3 +312,54 @@ def test_gemm_tn_256_operand_beyond_4gb(hip):
         assert float(dW[cols[8200]].abs().sum()) > 0      # a token beyond the 4 GB mark did land
     del dY, X, dW, ref
     torch.cuda.empty_cache()
+
+
+WAVE4_192 = 4
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 768, 768), (2427, 768, 3072), (8192, 2304, 768), (300, 384, 256), (16384, 768, 2304)])
+def test_four_wave_kernel_on_192_wide_tiles(hip, M, N, K):
+    """STONK_GEMM_WAVE4_192: 256x192 tiles (128x96 wave tiles, 4 x 3 MFMA blocks) - what AUTO takes for the N = 768
+    launches of the step. Plain product (ragged last row tile), the side-operand epilogues it is compiled for, the same
+    dropout mask as the 128x128 kernel, a device-side row count, bit-identical repeats; shapes it cannot take are refused."""
+    A, B = _rand((M, K), 0.5, 51), _rand((N, K), 0.05, 52)
+    ref = A.float() @ B.float().t()
+    out = _gemm(hip, A, B, kernel=WAVE4_192)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
+    for _ in range(5):
+        assert torch.equal(_gemm(hip, A, B, kernel=WAVE4_192), out)
+    bias = torch.randn(N, device="cuda")
+    resid = _rand((M, N), 1.0, 53)
+    out = _gemm(hip, A, B, flags=hip.EPI_BIAS, bias=bias, kernel=WAVE4_192)
+    torch.testing.assert_close(out.float(), ref + bias, rtol=2e-2, atol=2e-2)
+    out = _gemm(hip, A, B, flags=hip.EPI_RESID, resid=resid, kernel=WAVE4_192)
+    torch.testing.assert_close(out.float(), ref + resid.float(), rtol=2e-2, atol=3e-2)
+    out = _gemm(hip, A, B, flags=hip.EPI_BIAS | hip.EPI_RESID, bias=bias, resid=resid, kernel=WAVE4_192)
+    torch.testing.assert_close(out.float(), ref + bias + resid.float(), rtol=2e-2, atol=3e-2)
+    fl = hip.EPI_BIAS | hip.EPI_RESID | hip.EPI_DROPOUT
+    d192 = _gemm(hip, A, B, flags=fl, bias=bias, resid=resid, drop_p=0.1, seed=9, kernel=WAVE4_192).float() - resid.float()
+    d128 = _gemm(hip, A, B, flags=fl, bias=bias, resid=resid, drop_p=0.1, seed=9, kernel=T128).float() - resid.float()
+    pre = ref + bias
+    kept = (d192.abs() > 1e-3) | (pre.abs() < 1e-2)
+    assert abs(1.0 - kept.float().mean().item() - 0.1) < 0.02
+    assert (d192.abs() > 1e-3).eq(d128.abs() > 1e-3).float().mean().item() > 0.999      # one mask per (seed, row, column)
+    torch.testing.assert_close(torch.where(kept, d192, torch.zeros_like(d192)),
+                               torch.where(kept, pre / 0.9, torch.zeros_like(pre)), rtol=3e-2, atol=6e-2)
+    m_dev = torch.tensor([max(1, M - 37)], device="cuda", dtype=torch.int32)
+    C = torch.full((M, N), -7.0, device="cuda", dtype=torch.bfloat16)
+    _gemm(hip, A, B, C=C, m_dev=m_dev, kernel=WAVE4_192)
+    torch.testing.assert_close(C[:M - 37].float(), ref[:M - 37], rtol=2e-2, atol=2e-2)
+    assert (C[M - 37:] == -7.0).all()
+    # AUTO picks a tile width itself and agrees
+    auto = _gemm(hip, A, B, flags=hip.EPI_RESID, resid=resid)
+    torch.testing.assert_close(auto.float(), ref + resid.float(), rtol=2e-2, atol=3e-2)
+    with pytest.raises(hip.StonkHipError, match="-2"):   # no 192-wide instance for a GELU epilogue / fp32 output
+        _gemm(hip, A, B, flags=hip.EPI_BIAS | hip.EPI_GELU, bias=bias, kernel=WAVE4_192)
+    with pytest.raises(hip.StonkHipError, match="-2"):
+        _gemm(hip, A, B, torch.float32, flags=hip.EPI_OUT_F32, kernel=WAVE4_192)
+
+
+def test_192_wide_tiles_need_n_divisible_by_192(hip):
+    A, B = _rand((512, 256), 0.5, 61), _rand((256, 256), 0.05, 62)
+    with pytest.raises(hip.StonkHipError, match="-2"):
+        _gemm(hip, A, B, kernel=WAVE4_192)

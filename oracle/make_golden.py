@@ -496,6 +496,54 @@ def checkpoint_case(sm, pre, prepare_df_ref):
     print("checkpoint:", len(keys), "tensors;", sorted(os.listdir(ck)), "loss", float(out.loss))
 
 
+def unk_walk_case(pre, prepare_df_ref):
+    """G10 (row f1, ref:src/stonkgs/models/stonkgs_for_embeddings.py:50-155): the reference's own row builder for embedding
+    extraction - tokenised evidence | source walk [SEP] target walk [SEP], a walk of [UNK] ids for a node the pre-trained
+    KG does not know, both halves masked by replace_mlm_tokens - run on a small local vocabulary file, the G8 node table
+    and a random-walk TSV. Fixture: the three input files + the integer rows it yields under random.seed(5)."""
+    pre.prepare_df = prepare_df_ref      # (the import harness stubbed it; the embeddings module binds it at import)
+    emb = importlib.import_module("stonkgs.models.stonkgs_for_embeddings")
+    # transformers 5.x dropped the `encode_plus` spelling the reference (written against 4.x) calls; in 4.x it is what
+    # calling the tokenizer does for a single text, so the name is pointed at `__call__` for this run
+    from transformers import BertTokenizer
+
+    if not hasattr(BertTokenizer, "encode_plus"):
+        BertTokenizer.encode_plus = BertTokenizer.__call__
+    d = prepare_df_ref(os.path.join(OUT, "g8_table.tsv"))
+    names = [str(k) for k in d.keys()]
+    rng = np.random.RandomState(21)
+    walks_path = os.path.join(OUT, "g10_walks.tsv")
+    with open(walks_path, "w") as fh:
+        for n in names[:100]:                     # the last 20 nodes have an embedding but no stored walk
+            fh.write(n + "\t" + "\t".join(names[i] for i in rng.randint(0, len(names), 127)) + "\n")
+    words = ["the", "of", "and", "in", "protein", "kinase", "binds", "phosphorylates", "inhibits", "activates", "cell",
+             "expression", "receptor", "complex", "growth", "factor", "signal", "pathway", "increases", "decreases", "by",
+             "to", "a", "is", "with", "##s", "##ed", "##ing", "##ation", "tumor", "akt", "##1", "mtor", "p53", "mdm", "##2",
+             ".", ",", "(", ")", "-"]
+    vocab = ["[PAD]"] + [f"[unused{i}]" for i in range(1, 100)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words
+    # a local tokenizer directory (vocab.txt): the reference's `nlp_model_type` branch, BertTokenizer.from_pretrained(dir) -
+    # its default branch, BertTokenizerFast(vocab_file=...), builds an empty vocabulary under transformers 5.x
+    tok_dir = os.path.join(OUT, "g10_tokenizer")
+    os.makedirs(tok_dir, exist_ok=True)
+    with open(os.path.join(tok_dir, "vocab.txt"), "w") as fh:
+        fh.write("\n".join(vocab) + "\n")
+    rows = [(names[3], names[57], "AKT1 phosphorylates MDM2 and inhibits p53 expression in tumor cells."),
+            (names[99], "not-a-node", "The receptor complex activates the mTOR signaling pathway."),
+            ("unknown:1", names[110], "Growth factor binds to a kinase, (increasing) expression - unseenword."),
+            (names[0], names[1], "")]
+    random.seed(5)
+    out = list(emb.preprocess_df_for_embeddings_iter(rows, embedding_name_to_vector_path=os.path.join(OUT, "g8_table.tsv"),
+                                                     embedding_name_to_random_walk_path=walks_path,
+                                                     nlp_model_type=tok_dir))
+    res = {k: np.array([r[k] for r in out], dtype=np.int64) for k in out[0]}
+    res["sources"] = np.array([r[0] for r in rows])
+    res["targets"] = np.array([r[1] for r in rows])
+    res["evidences"] = np.array([r[2] for r in rows])
+    np.savez_compressed(os.path.join(OUT, "g10_embedding_rows.npz"), **res)
+    print("embedding rows:", res["input_ids"].shape, "unk ids in row 1:", int((res["input_ids"][1, 256:] == 100).sum()),
+          "text ids row 0 head:", res["input_ids"][0, :12].tolist())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "splits":     # only (re)generate G7
@@ -514,6 +562,7 @@ def main():
             pdf = import_reference_prepare_df()
             table_case(pdf)
             checkpoint_case(sm, pre, pdf)
+            unk_walk_case(pre, pdf)
         return
     # G1: tiny, every tensor stored (pins the oracle op for op)
     model_case("g1_tiny", sm, pre, orc.OracleConfig(vocab_size=300, kg_vocab_size=150, hidden_size=64, num_hidden_layers=2,
@@ -537,6 +586,7 @@ def main():
     pdf = import_reference_prepare_df()
     table_case(pdf)
     checkpoint_case(sm, pre, pdf)
+    unk_walk_case(pre, pdf)
 
 
 if __name__ == "__main__":

@@ -12,10 +12,11 @@ Same names, arguments and return layout; what changes is that rows are stacked i
 batch allowed) and that the embedding path runs the encoder only (``STonKGsForPreTraining.encode``): the reference's loop
 also evaluates both vocabulary-wide decoders and three cross-entropies per row and discards them.
 
-Out of scope here, as in SURVEY section 8: turning (source, target, evidence) triples into ``input_ids`` needs the
-BioBERT tokenizer, the node2vec table names and the random-walk file (``preprocess_df_for_embeddings``), none of which
-can be fetched offline - these helpers take rows that already have ``input_ids`` / ``attention_mask`` /
-``token_type_ids``."""
+``preprocess_df_for_embeddings`` / ``preprocess_df_for_embeddings_iter`` (ref:stonkgs_for_embeddings.py:26-155) turn
+(source, target, evidence) triples into those rows: tokenised evidence | source walk [SEP] target walk [SEP], a walk of
+[UNK] ids for a node the pre-trained KG does not know, both halves masked by ``replace_mlm_tokens`` - host-side integer
+work, bit-exact with the reference's own function for the same ``random`` state (tests/golden/g10_embedding_rows.npz).
+Everything is read from LOCAL files (the reference's defaults are hub / Zenodo downloads)."""
 from __future__ import annotations
 
 from typing import Iterable, Iterator, List, Optional, Sequence, Tuple
@@ -25,6 +26,72 @@ import torch
 from .stonkgs_model import STonKGsForPreTraining, STonKGsForSequenceClassification, SequenceClassifierOutput
 
 _COLUMNS = ("input_ids", "attention_mask", "token_type_ids")
+
+
+def _local_tokenizer(vocab_file_path=None, nlp_model_type=None):
+    """BERT WordPiece tokenizer from a local ``vocab.txt`` (file, or directory holding one). The reference builds
+    ``BertTokenizerFast(vocab_file=...)`` or ``BertTokenizer.from_pretrained(name)`` (ref:stonkgs_for_embeddings.py:91-97);
+    a hub name cannot be resolved offline."""
+    import os
+    import shutil
+    import tempfile
+
+    from transformers import BertTokenizer
+
+    if nlp_model_type is not None:
+        if not os.path.isdir(nlp_model_type):
+            raise FileNotFoundError(f"{nlp_model_type!r}: pass a local tokenizer directory (vocab.txt), hub names cannot be fetched")
+        return BertTokenizer.from_pretrained(nlp_model_type)
+    if vocab_file_path is None:
+        raise ValueError("pass vocab_file_path (a BERT vocab.txt) or nlp_model_type (a local tokenizer directory)")
+    # (`BertTokenizerFast(vocab_file=...)` as the reference spells it builds an EMPTY vocabulary under transformers 5.x:
+    # the file is handed over as a one-file tokenizer directory instead, which every version reads)
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(str(vocab_file_path), os.path.join(tmp, "vocab.txt"))
+        return BertTokenizer.from_pretrained(tmp)
+
+
+def preprocess_df_for_embeddings_iter(rows: Iterable[Tuple[str, str, str]], *, embedding_name_to_vector_path=None,
+                                      embedding_name_to_random_walk_path=None, vocab_file_path=None, nlp_model_type=None,
+                                      sep_id: Optional[int] = None, unk_id: Optional[int] = None, tokenizer=None):
+    """ref:src/stonkgs/models/stonkgs_for_embeddings.py:50-155, same names and defaults (sep 102, unk 100) except that
+    every path must be given (local files). ``tokenizer``: an already built HF tokenizer (optional)."""
+    from .data import replace_mlm_tokens
+    from .stonkgs_model import prepare_df
+
+    if embedding_name_to_vector_path is None or embedding_name_to_random_walk_path is None:
+        raise ValueError("embedding_name_to_vector_path and embedding_name_to_random_walk_path must be local TSV files")
+    sep_id = 102 if sep_id is None else sep_id
+    unk_id = 100 if unk_id is None else unk_id
+    kg_embed_dict = prepare_df(embedding_name_to_vector_path)
+    kg_name_to_idx = {key: i for i, key in enumerate(kg_embed_dict.keys())}       # TSV row order (quirk Q1's "preprocessing space")
+    random_walk_dict = prepare_df(embedding_name_to_random_walk_path)
+    random_walk_idx_dict = {k: [kg_name_to_idx[node] for node in v] for k, v in random_walk_dict.items()}
+    random_walk_length = len(next(iter(random_walk_idx_dict.values())))
+    half_length = random_walk_length * 2 + 2
+    if tokenizer is None:
+        tokenizer = _local_tokenizer(vocab_file_path, nlp_model_type)
+    vocab_len = len(tokenizer.vocab)
+    for source, target, evidence in rows:
+        token_type_ids = [0] * half_length + [1] * half_length
+        encoded = tokenizer(evidence, padding="max_length", truncation=True, max_length=half_length)
+        text_token_ids, text_attention_mask = list(encoded["input_ids"]), list(encoded["attention_mask"])
+        walk_s = random_walk_idx_dict[source] if source in random_walk_idx_dict else [unk_id] * random_walk_length
+        walk_t = random_walk_idx_dict[target] if target in random_walk_idx_dict else [unk_id] * random_walk_length
+        random_walks = walk_s + [sep_id] + walk_t + [sep_id]
+        attention_mask = text_attention_mask + [1] * half_length
+        masked_ids, masked_lm_labels = replace_mlm_tokens(tokens=text_token_ids, vocab_len=vocab_len)
+        ent_ids, ent_masked_lm_labels = replace_mlm_tokens(tokens=random_walks, vocab_len=len(kg_embed_dict))
+        yield {"input_ids": masked_ids + ent_ids, "attention_mask": attention_mask, "token_type_ids": token_type_ids,
+               "masked_lm_labels": masked_lm_labels, "ent_masked_lm_labels": ent_masked_lm_labels,
+               "next_sentence_labels": 0}
+
+
+def preprocess_df_for_embeddings(df, **kwargs):
+    """ref:stonkgs_for_embeddings.py:26-47: DataFrame with source / target / evidence columns -> DataFrame of model rows."""
+    import pandas as pd
+
+    return pd.DataFrame(preprocess_df_for_embeddings_iter(rows=df[["source", "target", "evidence"]].values, **kwargs))
 
 
 def _rows_of(data, indices: Optional[Sequence[int]]) -> List[dict]:

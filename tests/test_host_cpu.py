@@ -250,3 +250,31 @@ def test_bench_spawns_ranks_and_refuses_a_mismatched_launcher(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 2
+
+
+def test_embedding_row_builder_matches_the_reference():
+    """Row f1 (ref:src/stonkgs/models/stonkgs_for_embeddings.py:50-155): (source, target, evidence) -> model rows, against
+    rows the REFERENCE's own function yielded (oracle/make_golden.py f3: local tokenizer directory, the G8 node table, a
+    random-walk TSV, random.seed(5)): tokenised text, walks in TSV-row index space, [UNK] walks for unknown nodes, masks,
+    labels - every integer equal."""
+    import random
+
+    import pandas as pd
+
+    from stonkgs_amd.stonkgs_for_embeddings import preprocess_df_for_embeddings, preprocess_df_for_embeddings_iter
+
+    gold = dict(np.load(GOLDEN + "/g10_embedding_rows.npz"))
+    rows = list(zip(gold["sources"].tolist(), gold["targets"].tolist(), gold["evidences"].tolist()))
+    kw = dict(embedding_name_to_vector_path=GOLDEN + "/g8_table.tsv", embedding_name_to_random_walk_path=GOLDEN + "/g10_walks.tsv")
+    random.seed(5)
+    out = list(preprocess_df_for_embeddings_iter(rows, nlp_model_type=GOLDEN + "/g10_tokenizer", **kw))
+    for k in ("input_ids", "attention_mask", "token_type_ids", "masked_lm_labels", "ent_masked_lm_labels", "next_sentence_labels"):
+        assert np.array_equal(np.array([r[k] for r in out]), gold[k]), k
+    assert (gold["input_ids"][1, 256 + 128:256 + 255] == 100).sum() > 100     # the unknown target's walk is [UNK] ids
+    # the vocab-file spelling and the DataFrame wrapper give the same rows
+    random.seed(5)
+    df = preprocess_df_for_embeddings(pd.DataFrame(rows, columns=["source", "target", "evidence"]),
+                                      vocab_file_path=GOLDEN + "/g10_tokenizer/vocab.txt", **kw)
+    assert df["input_ids"].tolist() == gold["input_ids"].tolist() and list(df.columns)[:3] == ["input_ids", "attention_mask", "token_type_ids"]
+    with pytest.raises(FileNotFoundError):
+        next(preprocess_df_for_embeddings_iter(rows, nlp_model_type="dmis-lab/biobert-v1.1", **kw))

@@ -64,7 +64,9 @@ int stonk_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
 /* dx = LayerNorm'(dy) (dy first masked by the forward's output dropout when STONK_LN_DROPOUT);
  * dx_drop (nullable) = dropout-masked copy of dx for the branch that went through nn.Dropout before the residual
  * add; dgamma/dbeta (fp32, nullable) are ACCUMULATED - through per-workgroup partials when a workspace of
- * >= 1024 * 2 * H floats is passed (nullable: falls back to atomics). Autograd backward of the sites above. */
+ * >= 1024 * 2 * H floats is passed (nullable: falls back to atomics). Autograd backward of the sites above.
+ * stonk_layernorm_bwd_workspace_floats(rows, H) is the size to pass (the only launcher that takes a workspace). */
+int64_t stonk_layernorm_bwd_workspace_floats(int64_t rows, int H);
 int stonk_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                         void* dx, void* dx_drop, float* dgamma, float* dbeta, int64_t rows, int H, int flags,
                         float drop_p_in, uint32_t seed_in, float drop_p_out, uint32_t seed_out, float* partial_ws,

@@ -106,12 +106,14 @@ def lib():
             fn.restype = C.c_int
         handle.stonk_abi_version.argtypes = []
         handle.stonk_abi_version.restype = C.c_int
+        handle.stonk_layernorm_bwd_workspace_floats.argtypes = [_i64, _i32]   # a size query, not a launcher: returns the size
+        handle.stonk_layernorm_bwd_workspace_floats.restype = C.c_int64
         _lib = handle
     return _lib
 
 
 def exported_symbols():
-    return sorted(list(_SIGNATURES) + ["stonk_abi_version"])
+    return sorted(list(_SIGNATURES) + ["stonk_abi_version", "stonk_layernorm_bwd_workspace_floats"])
 
 
 def check(status: int, name: str) -> None:

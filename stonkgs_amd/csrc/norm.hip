@@ -668,6 +668,14 @@ extern "C" int stonk_layernorm_fwd(const void* x, const float* gamma, const floa
   return stonk_launch_status();
 }
 
+// Workspace query (launchers never allocate): floats of `partial_ws` with which stonk_layernorm_bwd sums
+// dgamma / dbeta through per-workgroup partials instead of contended atomics.
+extern "C" int64_t stonk_layernorm_bwd_workspace_floats(int64_t rows, int H) {
+  if (rows <= 0 || H <= 0) return 0;
+  const int grid = ln_grid(rows) < 1024 ? ln_grid(rows) : 1024;
+  return (int64_t)grid * 2 * H;
+}
+
 extern "C" int stonk_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd,
                                    const float* gamma, void* dx, void* dx_drop, float* dgamma, float* dbeta,
                                    int64_t rows, int H, int flags, float drop_p_in, uint32_t seed_in,

@@ -157,8 +157,10 @@ class Engine:
             self.gemm_timer.spans.setdefault(name, []).append((start, e))
 
     def ln_ws(self) -> torch.Tensor:
-        """Partial-sum workspace of the LayerNorm backward kernels (1024 workgroups x 2H floats)."""
-        return self.buf("ln.ws", (1024 * 2 * self.cfg.hidden_size,), F32)
+        """Partial-sum workspace of the LayerNorm backward kernels, sized by the library's own query for the largest row
+        count it can be asked for (every token of the largest batch seen so far)."""
+        n = int(hip.lib().stonk_layernorm_bwd_workspace_floats(1 << 30, self.cfg.hidden_size))
+        return self.buf("ln.ws", (n,), F32)
 
     def check_errors(self) -> None:
         """Raise for any flag the kernels set (one tiny D2H copy; call where a sync is acceptable)."""

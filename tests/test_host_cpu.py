@@ -94,12 +94,14 @@ def test_plan_buckets_covers_buffer_exactly():
 def test_library_exports_every_declared_symbol():
     """include/stonk_hip.h, the ctypes table and the built .so agree (no compute call: no GPU here)."""
     header = open(os.path.join(ROOT, "include", "stonk_hip.h")).read()
-    declared = set(re.findall(r"^int (stonk_\w+)\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t) (stonk_\w+)\(", header, flags=re.M))
     assert declared == set(_hip.exported_symbols())
     lib = ctypes.CDLL(_hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
     assert _hip.lib().stonk_abi_version() == 2
+    assert _hip.lib().stonk_layernorm_bwd_workspace_floats(32768, 768) == 1024 * 2 * 768   # (no GPU touched: a size query)
+    assert _hip.lib().stonk_layernorm_bwd_workspace_floats(0, 768) == 0
 
 
 def test_bad_arguments_are_rejected_without_touching_the_gpu():

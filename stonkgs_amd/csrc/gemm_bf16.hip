@@ -357,9 +357,7 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   //    (FFN-down / attention-output forward 157 against 174 us, dgrad + residual 152 against 177, dgrad through GELU' 172
   //    against 200; -1.4 ms per step together) - on 256x192 tiles where those quantise better (N = 768: two full rounds
   //    of the CUs instead of one and a half; another 8-21 % per launch);
-  //  * wide plain launches (fused QKV, the label-sparse decoders) stay on the eight-wave kernel: the four-wave one is
-  //    faster per launch there too (105 against 125 us) but draws more power, every other kernel of the step slows by
-  //    1-4 % and the step does not get shorter;
+  //  * the label-sparse decoders (fp16 / fp32 output) and wide launches that tile evenly by 256 stay on the eight-wave kernel;
   //  * everything else (N = 768 without a side operand, split-K atomics, small M) keeps the 128x128 tiles.
   const bool w4_side = (flags & (STONK_EPI_RESID | STONK_EPI_GELU_BWD)) != 0;
   int k = kernel;
@@ -368,6 +366,10 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
         // FFN-up (bias + GELU, with or without the saved GELU'): the four-wave kernel, 36.20 against 36.58 ms per step in
         // round 2's interleaved A/B (its GELU epilogue is the longest of the step; fused QKV on it changes nothing: 36.47 / 36.50)
         : (w4_ok && big && (flags & STONK_EPI_GELU) && out_mode == STONK_EPI_OUT_BF16) ? STONK_GEMM_WAVE4
+        // fused QKV (bias only, N = 2304 = 12 x 192: six full rounds of the CUs instead of four and a half): 35.24 against
+        // 35.70 ms per step on 256x192 tiles, where the same kernel on 256x256 tiles changed nothing
+        : (w4_ok && big && (flags & 0x1FC) == STONK_EPI_BIAS && N % 192 == 0 && N % 256 != 0 && out_mode == STONK_EPI_OUT_BF16)
+              ? STONK_GEMM_WAVE4
         : (v2_ok && big)                                                     ? STONK_GEMM_WAVE8
         // ... and the plain N = 768 launches (attention-output dgrad, the head transform's dgrad) since the four-wave kernel
         // has 256x192 tiles: 42.6 against 52.3 us (tools/bench_w4_tiles.py)

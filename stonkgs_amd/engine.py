@@ -262,7 +262,9 @@ class Engine:
             if wt is None:
                 wt = torch.zeros(cols, rpad, dtype=BF16, device=self.device)
                 self.P.wt[name] = wt
-            hip.call("stonk_transpose_f32_to_bf16", self.P.view(name).data_ptr(), wt.data_ptr(), rows, cols, rpad, st)
+            # from the bf16 MIRROR (the optimizer has just written it; bit-identical to casting the fp32 master, half the bytes)
+            src = self.P.bf16_view(name, padded=False)
+            hip.call("stonk_transpose_bf16", src.data_ptr(), cols, wt.data_ptr(), rpad, rows, cols, 0, 0, st)
 
     # ------------------------------------------------------------------ one BERT layer
     def layer_fwd(self, S: FlatStore, prefix: str, x, B, seq, mask, p_hid, p_att, lidx, save: Optional[dict]):

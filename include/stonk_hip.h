@@ -112,6 +112,11 @@ int stonk_attention_bwd(const void* q, const void* k, const void* v, int64_t ld,
 int stonk_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int cols,
                          float* colsum, const int* rows_dev, void* stream);
 int stonk_transpose_f32_to_bf16(const float* in, void* out, int64_t rows, int cols, int64_t ld_out, void* stream);
+/* n bf16 transposes in ONE launch (the W^T copies of every weight after an optimizer step). desc_dev: device array of n
+ * 56-byte entries {const void* in; void* out; int64 ld_in, ld_out, rows; int32 cols, first_tile, col_tiles, pad}, sorted
+ * by first_tile; an entry covers ceil(rows/64) * col_tiles tiles of 64x64 (col_tiles = ceil(cols/64)), total_tiles = the
+ * sum; cols % 8 == 0, ld_out >= roundup64(rows), rows past `rows` are written as zeros up to the tile edge. */
+int stonk_transpose_bf16_batched(const void* desc_dev, int n, int total_tiles, void* stream);
 int stonk_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 
 /* On-device dynamic masking: ids_in [B,S] -> ids_out [B,S] + text / entity labels [B,half]. Per half,

@@ -194,6 +194,54 @@ __global__ __launch_bounds__(256) void transpose_kernel(const SrcT* __restrict__
   }
 }
 
+// Batched form of the bf16 transpose: ONE launch refreshes every W^T copy of the model (57 tensors per optimizer step; as
+// separate launches they were 1.2 ms of mostly launch gaps and small grids on the optimizer stream). `desc` is a
+// device-side table of n entries {in, out, ld_in, ld_out, rows, cols, first_tile, tiles_per_row}; the grid is the total
+// number of 64x64 tiles and a workgroup finds its entry by bisection on first_tile.
+struct TransposeDesc {
+  const bf16* in;
+  bf16* out;
+  long ld_in, ld_out, rows;
+  int cols, first_tile, col_tiles, pad;
+};
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const TransposeDesc* __restrict__ desc, int n) {
+  __shared__ unsigned short tile[TT][TT + 2];
+  const int bid = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {   // last entry whose first_tile <= bid
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].first_tile <= bid) lo = mid;
+    else hi = mid - 1;
+  }
+  const TransposeDesc d = desc[lo];
+  const int tl = bid - d.first_tile;
+  const long r0 = (long)(tl / d.col_tiles) * TT;
+  const int c0 = (tl % d.col_tiles) * TT;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int rr = (t >> 3) + 32 * pass, cc = (t & 7) * 8;
+    const long r = r0 + rr;
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < d.rows && c0 + cc < d.cols) v = *(const u16x8*)(d.in + r * d.ld_in + c0 + cc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[rr][cc + j] = v[j];
+  }
+  __syncthreads();
+  const int oc = t >> 2, rb = (t & 3) * 16;
+  if (c0 + oc < d.cols) {
+    u16x8 o0, o1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o0[j] = tile[rb + j][oc];
+      o1[j] = tile[rb + 8 + j][oc];
+    }
+    bf16* dst = d.out + (long)(c0 + oc) * d.ld_out + r0 + rb;
+    *(u16x8*)dst = o0;
+    *(u16x8*)(dst + 8) = o1;
+  }
+}
+
 inline int ew_grid(long n) {
   long g = (n / 4 + 255) / 256;
   if (g < 1) g = 1;
@@ -252,6 +300,14 @@ extern "C" int stonk_transpose_bf16(const void* in, int64_t ld_in, void* out, in
   const dim3 grid((cols + TT - 1) / TT, (unsigned)rtiles);
   hipLaunchKernelGGL((transpose_kernel<bf16>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)in, (long)ld_in,
                      (bf16*)out, (long)ld_out, (long)rows, cols, colsum, rows_dev);
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_transpose_bf16_batched(const void* desc_dev, int n, int total_tiles, void* stream) {
+  STONK_CHECK_ARG(desc_dev && n > 0 && total_tiles > 0, STONK_EINVAL);
+  STONK_CHECK_ARG((uintptr_t)desc_dev % 8 == 0, STONK_EALIGN);
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream,
+                     (const TransposeDesc*)desc_dev, n);
   return stonk_launch_status();
 }
 

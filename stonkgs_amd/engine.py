@@ -101,6 +101,7 @@ class Engine:
         self._opt_stream: Optional[torch.cuda.Stream] = None
         self._params_ready: Optional[torch.cuda.Event] = None
         self._wgrad_done: Dict[int, torch.cuda.Event] = {}   # layer parity -> side-stream event after its last wgrad
+        self._wt_desc = None   # (device table, entries, tiles) of the batched W^T refresh
         # development switches, read ONCE here (tools/ab_step.py builds a fresh engine per arm): the 128x128 weight-gradient
         # kernel everywhere / the CU share of the side-stream weight gradients / the 768 x 768 gradients on the four-wave
         # kernel as well / QKV and backbone FFN-up forward on the four-wave kernel
@@ -250,7 +251,18 @@ class Engine:
         if bf16_mirror:
             for s in (self.P, self.BB):
                 hip.call("stonk_cast_f32_to_bf16", s.data.data_ptr(), s.bf16.data_ptr(), s.numel, st)
-        H = self.cfg.hidden_size
+        if self._wt_desc is None:
+            self._wt_desc = self._build_wt_table()
+        desc, n, tiles = self._wt_desc
+        hip.call("stonk_transpose_bf16_batched", desc.data_ptr(), n, tiles, st)
+
+    def _build_wt_table(self):
+        """Descriptor table of the batched W^T refresh (stonk_transpose_bf16_batched): one entry per dgrad weight - source =
+        its slice of the bf16 mirror (the optimizer has just written it; bit-identical to casting the fp32 master), destination
+        = the [in, out_padded] copy. Addresses are stable for the life of the store, so the table is built once."""
+        import struct
+
+        entries, first = [], 0
         for name, (off, shape, pshape) in self.P.index.items():
             if len(shape) != 2 or not name.endswith(".weight") or shape[0] < 64:
                 continue
@@ -262,9 +274,12 @@ class Engine:
             if wt is None:
                 wt = torch.zeros(cols, rpad, dtype=BF16, device=self.device)
                 self.P.wt[name] = wt
-            # from the bf16 MIRROR (the optimizer has just written it; bit-identical to casting the fp32 master, half the bytes)
             src = self.P.bf16_view(name, padded=False)
-            hip.call("stonk_transpose_bf16", src.data_ptr(), cols, wt.data_ptr(), rpad, rows, cols, 0, 0, st)
+            col_tiles = (cols + 63) // 64
+            entries.append(struct.pack("<QQqqqiiii", src.data_ptr(), wt.data_ptr(), cols, rpad, rows, cols, first, col_tiles, 0))
+            first += ((rows + 63) // 64) * col_tiles
+        raw = torch.frombuffer(bytearray(b"".join(entries)), dtype=torch.uint8).to(self.device)
+        return raw, len(entries), first
 
     # ------------------------------------------------------------------ one BERT layer
     def layer_fwd(self, S: FlatStore, prefix: str, x, B, seq, mask, p_hid, p_att, lidx, save: Optional[dict]):

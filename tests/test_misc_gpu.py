@@ -47,6 +47,31 @@ def test_transpose_f32_and_cast(hip):
     assert torch.equal(y, w.flatten()[: y.numel()].to(torch.bfloat16))
 
 
+def test_batched_transpose_refreshes_many_tensors_in_one_launch(hip):
+    """stonk_transpose_bf16_batched: a device-side table of (in, out, ld_in, ld_out, rows, cols, first_tile, col_tiles)
+    entries, one 64x64 tile per workgroup - the W^T copies of every weight after an optimizer step. Ragged row counts
+    (the text decoder's 28 996 rows of a 29 056-row slab) are zero-filled up to the tile edge."""
+    import struct
+
+    shapes = [(768, 768), (1000, 256), (3072, 768), (128, 64), (28996 % 4096 + 4096, 128)]
+    srcs, outs, entries, first = [], [], [], 0
+    for i, (rows, cols) in enumerate(shapes):
+        x = _rand((rows, cols), 1.0, 40 + i)
+        rpad = (rows + 63) // 64 * 64
+        out = torch.full((cols, rpad), 7.0, device="cuda", dtype=torch.bfloat16)
+        col_tiles = (cols + 63) // 64
+        entries.append(struct.pack("<QQqqqiiii", hip.ptr(x), hip.ptr(out), cols, rpad, rows, cols, first, col_tiles, 0))
+        first += ((rows + 63) // 64) * col_tiles
+        srcs.append(x)
+        outs.append(out)
+    table = torch.frombuffer(bytearray(b"".join(entries)), dtype=torch.uint8).cuda()
+    hip.call("stonk_transpose_bf16_batched", hip.ptr(table), len(shapes), first, hip.stream_ptr())
+    torch.cuda.synchronize()
+    for x, out, (rows, cols) in zip(srcs, outs, shapes):
+        assert torch.equal(out[:, :rows], x.t())
+        assert (out[:, rows:] == 0).all()
+
+
 def test_label_compact_gather_scatter(hip):
     B, half, S, H = 5, 256, 512, 64
     g = torch.Generator().manual_seed(0)

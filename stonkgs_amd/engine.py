@@ -102,12 +102,12 @@ class Engine:
         self._params_ready: Optional[torch.cuda.Event] = None
         self._wgrad_done: Dict[int, torch.cuda.Event] = {}   # layer parity -> side-stream event after its last wgrad
         self._wt_desc = None   # (device table, entries, tiles) of the batched W^T refresh
-        # development switches, read ONCE here (tools/ab_step.py builds a fresh engine per arm): the 128x128 weight-gradient
-        # kernel everywhere / the CU share of the side-stream weight gradients / the 768 x 768 gradients on the four-wave
-        # kernel as well / QKV and backbone FFN-up forward on the four-wave kernel
+        # development switches, read ONCE here: the 128x128 weight-gradient kernel everywhere / the CU share of the
+        # side-stream weight gradients
         self.tn_v1 = bool(os.environ.get("STONK_TN_V1"))
         self.tn_cus = int(os.environ.get("STONK_TN_CUS", "160"))
-        self.tn_min_tiles = 36 if os.environ.get("STONK_TN_SMALL") else 100
+        self.tn_min_tiles = 36    # 128x128 tiles of an output from which the four-wave kernel takes the gradient: 36 = the
+                                  # 768 x 768 ones too (35.67 against 35.79 ms per step with 100, tools/sweep_engine_int.py)
 
     # ------------------------------------------------------------------ plumbing
     def buf(self, name: str, shape, dtype=BF16, zero=False) -> torch.Tensor:

@@ -25,9 +25,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM-side bytes per launch of the dominant kernel, from separate rocprofv3 --pmc passes over this command:
-# gemm_tn_w4_kernel (12L/768, average of its 37 launches per step): 337.7 MB fetched (FETCH_SIZE doubled, the gfx950
-# correction of MI355X_MICROARCH.md) + 61.1 MB of float atomics written (profiles/r01_final_pmc_traffic.csv)
-TRAFFIC_BYTES = {("150k", "tn_w4"): 398.8e6}
+# gemm_tn_w4_kernel (12L/768, average of its 50 launches per step): 283.9 MB fetched (FETCH_SIZE doubled, the gfx950
+# correction of MI355X_MICROARCH.md) + 57.2 MB of float atomics written (profiles/r02_pmc_traffic.csv; round 1, 37
+# launches: 337.7 + 61.1)
+TRAFFIC_BYTES = {("150k", "tn_w4"): 341.1e6}
 KERNEL_NOTES = {
     "tn_w4": "gemm_tn_w4_kernel (weight + bias gradients: bf16 MFMA 32x32x16, 256x256 tiles over 64-token steps, four waves, "
              "transposed LDS reads, split-K fp32 atomics)",
@@ -251,6 +252,15 @@ def main():
             trainer.training_step(model, batches[i % len(batches)])
         torch.cuda.synchronize()
         timer = model.engine.gemm_timer
+        # the same launches ALONE (serial order: no second stream, every CU theirs) in two more steps - a labelled second
+        # figure, never the headline: in the step the kernel shares the chip with the dgrad chain and queues for CUs
+        model.engine.gemm_timer = GemmTimer()
+        model.engine.overlap_wgrad = False
+        for i in range(2):
+            trainer.training_step(model, batches[i % len(batches)])
+        torch.cuda.synchronize()
+        alone = model.engine.gemm_timer
+        model.engine.overlap_wgrad = True
         model.engine.gemm_timer = None
         kinds = timer.kinds()
         # the dominant SINGLE kernel of the rocprofv3 summary ("nt" lumps several forward / dgrad kernels together)
@@ -269,6 +279,10 @@ def main():
                     "timing": "HIP events around every launch on the stream the step launches it on (second stream, "
                               "CU share as in the timed steps), two instrumented steps after the timed region",
                     "launches_per_step": s["launches"] // 2,
+                    "alone": {"what": "the same launches without the second stream (serial order, all 256 CUs): the kernel's own "
+                                      "efficiency, not what the step achieves",
+                              "frac": round(alone.summarize(dom)["flops"] / alone.summarize(dom)["seconds"] / 1e12 / PEAK_BF16_TFLOPS, 4),
+                              "avg_launch_us": round(alone.summarize(dom)["seconds"] / max(1, alone.summarize(dom)["launches"]) * 1e6, 1)},
                     "avg_launch_us": round(s["seconds"] / s["launches"] * 1e6, 1),
                     "avg_launch_gflop": round(s["flops"] / s["launches"] / 1e9, 2),
                     "by_kernel": {k: {"launches_per_step": timer.summarize(k)["launches"] // 2,

@@ -98,9 +98,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmArgs p) {
     if (w >= total) return false;
     int idx = w;
     if ((G & 7) == 0) {
+      // Round r hands items [r G, r G + n_r) to the workgroups so that every XCD (blockIdx & 7) takes ONE contiguous run
+      // of them - also in a ragged round (n_r < G: the last one, or the only one when a device-side row count leaves fewer
+      // items than the grid was sized for). The label-sparse decoder dgrad is such a launch: 30 live tiles x 8 K splits =
+      // 240 items on a grid of 256; in natural order every XCD saw every K split and each L2 re-fetched the 269 MB weight
+      // (2.7 GB of fabric reads per launch for 1.1 GB of operands); with the runs, XCD x works on K split x alone.
       const int r = w / G, b = w - r * G;
-      const int cand = r * G + (b & 7) * (G >> 3) + (b >> 3);
-      if ((r + 1) * G <= total) idx = cand;  // full rounds only; the ragged last round keeps natural order
+      const int n_r = total - r * G < G ? total - r * G : G;
+      const int x = b & 7, s = b >> 3, q = n_r >> 3, rem = n_r & 7;
+      if (s >= q + (x < rem ? 1 : 0)) return false;   // (only in a ragged round, which is the last)
+      idx = r * G + x * q + (x < rem ? x : rem) + s;
     }
     const int ks = idx / per_split;
     const int tt = idx - ks * per_split;

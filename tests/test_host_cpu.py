@@ -206,13 +206,14 @@ def test_bench_contract_constants():
         sys.argv = old
     assert a.gpus == 1 and 0 < a.steps <= 50 and 0 < a.warmup <= 10 and a.batch == 64
     assert bench.PEAK_BF16_TFLOPS == 2500.0
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_final_bench.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_final_bench.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "encoder_path"):
         assert key in line, key
     assert line["metric"] == metric and line["config"]["workload"] and line["vs_baseline"] is None
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
-    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "alone", "timing"} <= set(line["roofline"])
+    assert line["roofline"]["frac"] <= line["roofline"]["alone"]["frac"]   # the in-step figure is the headline, not the alone one
+    assert {"value", "unit", "cores", "kind", "sample", "at_8_threads"} <= set(line["cpu_baseline"])
 
 
 def test_bench_spawns_ranks_and_refuses_a_mismatched_launcher(monkeypatch):

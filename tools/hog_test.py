@@ -1,5 +1,5 @@
 """How long does a persistent one-workgroup-per-CU kernel take when some CUs are held by another stream's kernel (as RCCL's
-collectives hold them during data-parallel backward)? Builds tools/scratch/hog.hip on the GPU box, then times the
+collectives hold them during data-parallel backward)? Builds tools/hog_kernel.hip on the GPU box, then times the
 weight-gradient kernel and the persistent NT kernel alone and beside a 500 us, 32-workgroup hog."""
 import ctypes
 import os
@@ -16,7 +16,7 @@ from stonkgs_amd import _hip as hip  # noqa: E402
 out_dir = os.path.join(ROOT, "gpurun_out")
 os.makedirs(out_dir, exist_ok=True)
 so = os.path.join(out_dir, "libhog.so")
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", os.path.join(ROOT, "tools/scratch/hog.hip"), "-o", so])
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", os.path.join(ROOT, "tools/hog_kernel.hip"), "-o", so])
 hog = ctypes.CDLL(so)
 hog.hog_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 hip.lib()

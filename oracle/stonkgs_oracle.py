@@ -319,7 +319,9 @@ def train_step(sd: Dict[str, Tensor], cfg: OracleConfig, kg_table: Tensor, batch
             m = state.m.setdefault(k, torch.zeros_like(sd[k]))
             v = state.v.setdefault(k, torch.zeros_like(sd[k]))
             p = sd[k]
-            p.mul_(1 - lr * weight_decay)
+            # hf:trainer.py get_decay_parameter_names: biases and LayerNorm parameters are not decayed
+            if weight_decay and not (k.endswith(".bias") or "LayerNorm" in k):
+                p.mul_(1 - lr * weight_decay)
             m.mul_(b1).add_(g, alpha=1 - b1)
             v.mul_(b2).addcmul_(g, g, value=1 - b2)
             denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)

@@ -65,6 +65,9 @@ class FusedAdamW:
     def __init__(self, store: FlatStore, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0):
         self.store = store
         self.betas, self.eps, self.weight_decay, self.max_grad_norm = betas, eps, weight_decay, max_grad_norm
+        # HF Trainer decays every parameter except biases and LayerNorm weights (hf:trainer.py get_decay_parameter_names);
+        # the reference trains with weight_decay = 0, so this only matters to a caller who sets it
+        self.decayed = [name for name in store.index if name.endswith(".weight") and "LayerNorm" not in name]
         self.m = torch.zeros_like(store.data)
         self.v = torch.zeros_like(store.data)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=store.data.device)
@@ -77,8 +80,12 @@ class FusedAdamW:
         b1, b2 = self.betas
         self.gnorm_sq.zero_()
         hip.call("stonk_sumsq_f32", s.grad.data_ptr(), s.numel, self.gnorm_sq.data_ptr(), st)
+        if self.weight_decay:   # decoupled decay, p *= 1 - lr * wd, on the decayed tensors only and before the Adam update
+            for name in self.decayed:   # (torch.optim.AdamW's order); the fused kernel below then runs with wd = 0
+                v = s.view(name, padded=True)
+                hip.call("stonk_scale_f32", v.data_ptr(), v.numel(), 1.0 - lr * self.weight_decay, st)
         hip.call("stonk_adamw_step", s.data.data_ptr(), s.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                 s.bf16.data_ptr(), s.numel, lr, b1, b2, self.eps, self.weight_decay, 1.0 - b1 ** self.step_count,
+                 s.bf16.data_ptr(), s.numel, lr, b1, b2, self.eps, 0.0, 1.0 - b1 ** self.step_count,
                  1.0 - b2 ** self.step_count, self.gnorm_sq.data_ptr(), self.max_grad_norm, grad_scale, st)
 
     def last_grad_norm(self, grad_scale: float = 1.0) -> float:

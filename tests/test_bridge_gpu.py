@@ -157,3 +157,35 @@ def test_hf_trainer_two_steps(hip, tmp_path):
         d0 = (a[k].detach() - sd[k].cuda()).flatten()
         d1 = (b[k].detach() - sd[k].cuda()).flatten()
         assert torch.nn.functional.cosine_similarity(d0, d1, dim=0).item() > 0.9, k
+
+
+def test_weight_decay_skips_biases_and_layernorm_like_hf(hip):
+    """`TrainingArguments.weight_decay` (0 in the reference's run): the fused optimizer decays what HF Trainer decays - every
+    parameter except biases and LayerNorm weights (hf:trainer.py get_decay_parameter_names) - checked against the oracle,
+    whose grouping is pinned against torch.optim.AdamW in tests/test_oracle_golden.py. lr and decay are large on purpose."""
+    from stonkgs_amd.data import synthetic_batch
+    from stonkgs_amd.stonkgs_pretraining import Trainer, TrainingArguments
+
+    cfg, sd, tsv_rows, _, _, _ = load_case("g2_hipsmall")
+    batches = [synthetic_batch(3, cfg.vocab_size, cfg.kg_vocab_size, cfg.max_position_embeddings, seed=330 + i, min_text=16)
+               for i in range(2)]
+    model = _build(cfg, sd, tsv_rows)
+    tr = Trainer(model, TrainingArguments(max_steps=200, learning_rate=1e-2, weight_decay=0.5, per_device_train_batch_size=3))
+    for b in batches:
+        tr.training_step(model, b)
+    with torch.no_grad():
+        table = orc.build_kg_table(tsv_rows, orc.special_vectors(sd, cfg))
+    osd = {k: v.clone() for k, v in sd.items()}
+    state = orc.AdamState()
+    for b in batches:
+        orc.train_step(osd, cfg, table, b, state, base_lr=1e-2, max_steps=200, weight_decay=0.5)
+    p = dict(model.named_parameters())
+    for k in ("bert.encoder.layer.0.output.dense.weight", "cls.predictions.entity_decoder.weight",
+              "bert.embeddings.position_embeddings.weight"):      # decayed: shrunk by (1 - lr wd) per step besides the Adam move
+        got, ref = p[k].detach().cpu(), osd[k]
+        assert float((got - ref).norm() / ref.norm()) < 2e-2, k
+        assert float(ref.norm() / sd[k].norm()) < 0.995          # (the decay is visible at all)
+    for k in ("bert.encoder.layer.0.output.LayerNorm.weight", "bert.encoder.layer.1.intermediate.dense.bias"):   # not decayed
+        got, ref = p[k].detach().cpu(), osd[k]
+        assert float((got - ref).abs().max()) < 2.5e-2, k          # two Adam steps of lr = 1e-2 at the very worst
+        assert float((got - ref).norm() / ref.norm()) < 2e-2 or "bias" in k

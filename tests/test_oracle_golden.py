@@ -223,3 +223,35 @@ def test_reference_written_checkpoint_and_tsv_table():
     for e in (7, 101, 104):        # quirk Q1 through the TSV: id 101 -> row 100, id 104 -> row 101
         np.testing.assert_array_equal(table[e].numpy(), gold[f"table_row_{e}"].astype(np.float32))
     np.testing.assert_allclose(table[102].numpy(), gold["special_102"], rtol=1e-5, atol=2e-6)
+
+
+def test_weight_decay_grouping_matches_torch_adamw_with_hf_groups():
+    """The oracle's decoupled weight decay (unused by the reference, which trains with 0) against torch.optim.AdamW with the
+    two parameter groups HF Trainer builds (hf:trainer.py get_decay_parameter_names: no decay on biases / LayerNorm)."""
+    cfg, sd, tsv_rows, batch, gold, meta = load_case("g1_tiny")
+    with torch.no_grad():
+        table = _table(cfg, sd, tsv_rows)
+    names = orc.trainable_names(sd)
+    params = {k: torch.nn.Parameter(sd[k].clone()) for k in names}
+    decay = [params[k] for k in names if not (k.endswith(".bias") or "LayerNorm" in k)]
+    rest = [params[k] for k in names if (k.endswith(".bias") or "LayerNorm" in k)]
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.1}, {"params": rest, "weight_decay": 0.0}], lr=1e-2,
+                            betas=(0.9, 0.999), eps=1e-8)
+    osd = {k: v.clone() for k, v in sd.items()}
+    state = orc.AdamState()
+    for step in range(2):
+        work = dict(sd)
+        work.update(params)
+        loss = orc.forward(work, cfg, table, **batch)["loss"]
+        opt.zero_grad()
+        loss.backward()
+        for p in params.values():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+        for g in opt.param_groups:
+            g["lr"] = orc.linear_schedule_lr(1e-2, step, 200)
+        opt.step()
+        orc.train_step(osd, cfg, table, batch, state, base_lr=1e-2, max_steps=200, weight_decay=0.1)
+    for k in names:
+        np.testing.assert_allclose(osd[k].numpy(), params[k].detach().numpy(), rtol=0, atol=3e-6, err_msg=k)

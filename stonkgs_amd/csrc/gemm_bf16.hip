@@ -368,7 +368,7 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
         : (w4_ok && big && (flags & STONK_EPI_GELU) && out_mode == STONK_EPI_OUT_BF16) ? STONK_GEMM_WAVE4
         // fused QKV (bias only, N = 2304 = 12 x 192: six full rounds of the CUs instead of four and a half): 35.24 against
         // 35.70 ms per step on 256x192 tiles, where the same kernel on 256x256 tiles changed nothing
-        : (w4_ok && big && (flags & 0x1FC) == STONK_EPI_BIAS && N % 192 == 0 && N % 256 != 0 && out_mode == STONK_EPI_OUT_BF16)
+        : (w4_ok && big && (flags & 0x1FC) == STONK_EPI_BIAS && N % 192 == 0 && out_mode == STONK_EPI_OUT_BF16)
               ? STONK_GEMM_WAVE4
         : (v2_ok && big)                                                     ? STONK_GEMM_WAVE8
         // ... and the plain N = 768 launches (attention-output dgrad, the head transform's dgrad) since the four-wave kernel

@@ -187,10 +187,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        from datetime import timedelta
+
+        limit = timedelta(minutes=5)   # a rank that never arrives becomes an error on the others, not an endless wait
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev), timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
     from stonkgs_amd.config import STonKGsConfig
     from stonkgs_amd.data import synthetic_batch
     from stonkgs_amd.stonkgs_model import STonKGsForPreTraining

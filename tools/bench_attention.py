@@ -21,7 +21,7 @@ out = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16)
 lse = torch.empty(B, NH, S, device="cuda")
 delta = torch.empty(B, NH, S, device="cuda")
 dqkv = torch.zeros_like(qkv)
-p, seed = 0.1, 3
+p, seed = float(os.environ.get("P", 0.1)), 3
 
 
 def fwd():

@@ -81,6 +81,10 @@ def parse():
                     help="150k = BASELINE config 2/3 (12L/768h, the headline); 24L1024 = config 4 (synthetic scale-up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-alone", action="store_true",
+                    help="two more instrumented steps WITHOUT the second stream: the dominant kernel's own efficiency as a "
+                         "labelled extra field (off by default, so that a rocprofv3 summary of the default command holds "
+                         "in-step launches only and reproduces roofline.frac)")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = MODELS[args.model]["batch"]
@@ -255,15 +259,17 @@ def main():
             trainer.training_step(model, batches[i % len(batches)])
         torch.cuda.synchronize()
         timer = model.engine.gemm_timer
-        # the same launches ALONE (serial order: no second stream, every CU theirs) in two more steps - a labelled second
-        # figure, never the headline: in the step the kernel shares the chip with the dgrad chain and queues for CUs
-        model.engine.gemm_timer = GemmTimer()
-        model.engine.overlap_wgrad = False
-        for i in range(2):
-            trainer.training_step(model, batches[i % len(batches)])
-        torch.cuda.synchronize()
-        alone = model.engine.gemm_timer
-        model.engine.overlap_wgrad = True
+        # (--roofline-alone) the same launches ALONE (serial order: no second stream, every CU theirs) in two more steps - a
+        # labelled second figure, never the headline: in the step the kernel shares the chip with the dgrad chain
+        alone = None
+        if args.roofline_alone:
+            model.engine.gemm_timer = GemmTimer()
+            model.engine.overlap_wgrad = False
+            for i in range(2):
+                trainer.training_step(model, batches[i % len(batches)])
+            torch.cuda.synchronize()
+            alone = model.engine.gemm_timer
+            model.engine.overlap_wgrad = True
         model.engine.gemm_timer = None
         kinds = timer.kinds()
         # the dominant SINGLE kernel of the rocprofv3 summary ("nt" lumps several forward / dgrad kernels together)
@@ -282,10 +288,11 @@ def main():
                     "timing": "HIP events around every launch on the stream the step launches it on (second stream, "
                               "CU share as in the timed steps), two instrumented steps after the timed region",
                     "launches_per_step": s["launches"] // 2,
-                    "alone": {"what": "the same launches without the second stream (serial order, all 256 CUs): the kernel's own "
-                                      "efficiency, not what the step achieves",
-                              "frac": round(alone.summarize(dom)["flops"] / alone.summarize(dom)["seconds"] / 1e12 / PEAK_BF16_TFLOPS, 4),
-                              "avg_launch_us": round(alone.summarize(dom)["seconds"] / max(1, alone.summarize(dom)["launches"]) * 1e6, 1)},
+                    "alone": None if alone is None else {
+                        "what": "the same launches without the second stream (serial order, all 256 CUs): the kernel's own "
+                                "efficiency, not what the step achieves",
+                        "frac": round(alone.summarize(dom)["flops"] / alone.summarize(dom)["seconds"] / 1e12 / PEAK_BF16_TFLOPS, 4),
+                        "avg_launch_us": round(alone.summarize(dom)["seconds"] / max(1, alone.summarize(dom)["launches"]) * 1e6, 1)},
                     "avg_launch_us": round(s["seconds"] / s["launches"] * 1e6, 1),
                     "avg_launch_gflop": round(s["flops"] / s["launches"] / 1e9, 2),
                     "by_kernel": {k: {"launches_per_step": timer.summarize(k)["launches"] // 2,

@@ -74,8 +74,8 @@ def gflop_per_pair(cfg) -> float:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 64, BASELINE config 2)")
     ap.add_argument("--model", choices=sorted(MODELS), default="150k",
                     help="150k = BASELINE config 2/3 (12L/768h, the headline); 24L1024 = config 4 (synthetic scale-up)")

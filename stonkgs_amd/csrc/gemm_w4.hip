@@ -9,7 +9,7 @@
 //
 // Operands travel global -> registers -> LDS -> fragment registers. With one wave per SIMD every instruction the wave
 // issues competes with its own MFMAs, and an LDS-DMA piece (global_load_lds_dwordx4) costs the issuing wave 60+ cycles
-// - measured on the first version of this kernel as 240 us of a 1017 us 8192^3 run (STONK_W4_VAR experiments) - where a
+// - measured on the first version of this kernel as 240 us of a 1017 us 8192^3 run (timing builds with the VAR template parameter) - where a
 // plain 16-byte load and a ds_write_b128 cost a few cycles each.
 //
 // Schedule. The two K-tile stages (A image 256 rows x 128 B + B image, XOR-swizzled, 64 KiB each) alternate; a K tile

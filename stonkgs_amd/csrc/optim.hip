@@ -13,7 +13,7 @@ namespace {
 // Sum of squares in a FIXED order: every block leaves its partial sum in a slot, the last block to finish (ticket) adds
 // the slots up in index order. With one atomicAdd per block the result depended on arrival order in its last bits - and
 // with it the clip coefficient and every parameter update, so data-parallel ranks holding identical summed gradients
-// drifted apart by an ulp per step (found with tools/dp2_gloo_gpu.py). One optimizer stream per process is assumed
+// drifted apart by an ulp per step (found with tools/dp_check.py). One optimizer stream per process is assumed
 // (the slots are library globals).
 constexpr int SUMSQ_MAX_BLOCKS = 1024;
 __device__ float g_sumsq_part[SUMSQ_MAX_BLOCKS];

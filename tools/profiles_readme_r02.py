@@ -84,6 +84,10 @@ launch reading the bf16 mirror.
 * One batched launch for the W^T refresh instead of 57: 35.75 against 35.73 ms - kept for the shorter launch stream, not for time.
 * XCD-contiguous work-item runs in ragged rounds (the decoder dgrad's 240 items on a grid of 256): 534 against 542 us for the
   launch - kept (less fabric traffic), not a step-time change.
+* Keep-bits of the attention dropout stored by the forward (one bit per (query, key), 25 MB per layer) and read by the
+  backward kernels instead of re-hashing: bitwise identical results, but the forward's 32 ballot stores per K tile cost it
+  +39 us (128.9 -> 167.9), the dQ kernel - the masks as SGPR lane masks of a `v_cndmask`, fetched by scalar loads - gained
+  3 us (160.3 -> 157.3: the scalar loads' latency replaced the hash), dK/dV 18 us (215.0 -> 197.3): +18 us per layer, reverted.
 * Attention kernels without dropout, alone: forward 89.5 us (127.6 with), dQ 127 (165), dK/dV 194 (221): the counter-based
   mask costs 38 / 38 / 27 us per layer - the price of regenerating it instead of storing S x S bits.
 

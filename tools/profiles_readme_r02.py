@@ -88,6 +88,12 @@ launch reading the bf16 mirror.
   backward kernels instead of re-hashing: bitwise identical results, but the forward's 32 ballot stores per K tile cost it
   +39 us (128.9 -> 167.9), the dQ kernel - the masks as SGPR lane masks of a `v_cndmask`, fetched by scalar loads - gained
   3 us (160.3 -> 157.3: the scalar loads' latency replaced the hash), dK/dV 18 us (215.0 -> 197.3): +18 us per layer, reverted.
+* Phase-staggered persistent GEMMs (workgroup b starting (b & 3) quarter K loops late, so that the CUs are not all in their
+  HBM-bound epilogues at once - the hypothesis of DESIGN section 7): no gain alone where epilogues are heavy (FFN-up forward
+  237-272 us lockstep, 253-266 staggered; dgrad through GELU' 191 / 192) and a loss where rounds are few (dgrad + residual
+  155 -> 181, FFN-down forward 161 -> 185): the late starters' tail costs more than overlapping the epilogues saves. What
+  the FFN-up epilogue does cost is VALU: 23 issue slots per output element (erf by rcp + exp, GELU', two conversions), as
+  long as its twelve-K-tile loop.
 * Attention kernels without dropout, alone: forward 89.5 us (127.6 with), dQ 127 (165), dK/dV 194 (221): the counter-based
   mask costs 38 / 38 / 27 us per layer - the price of regenerating it instead of storing S x S bits.
 

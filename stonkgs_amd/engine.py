@@ -83,15 +83,16 @@ class Engine:
         self.overlap_wgrad = True
         # Set by the trainer when gradients are all-reduced while backward runs (world size > 1): RCCL's kernels then hold
         # some CUs for the length of a collective, and a PERSISTENT one-workgroup-per-CU kernel with a static tile split
-        # would wait for them (its late workgroups own a share of the tiles). Backward's only such launch on the main
-        # stream (dgrad through GELU) then takes the 128x128 kernel, whose grid the hardware schedules dynamically.
+        # would wait for them (its late workgroups own a share of the tiles). Backward's persistent launches on the main
+        # stream (the dgrad GEMMs of every layer, `_kernel(site, True)`) then take the 128x128 kernel, whose grid the
+        # hardware schedules dynamically.
         self.comm_overlap = False
         self.decoder_dgrad_256 = True
         # Which of the library's three NT kernels runs a launch is the LIBRARY's choice (STONK_GEMM_AUTO: from shape and
         # epilogue, stonk_gemm_nt_bf16) - except where the engine knows what the library cannot: that an all-reduce is
         # running beside backward (comm_overlap -> the dynamically scheduled 128x128 kernel for the persistent launches).
         # `kernel_for` lets a tool pin a site for an A/B (tools/ab_step.py): "qkv", "attn_out", "ffn_up", "ffn_down",
-        # "dgrad_gelu", "dgrad_resid", "dgrad_attn_out" -> hip.GEMM_*.
+        # "dgrad_gelu", "dgrad_resid", "dgrad_attn_out", "dgrad_head" -> hip.GEMM_*.
         self.kernel_for: Dict[str, int] = {}
         self.f16_logits = True      # label-sparse decoder logits in fp16 (False: fp32, 4 more bytes of HBM traffic per logit)
         self._wstream: Optional[torch.cuda.Stream] = None

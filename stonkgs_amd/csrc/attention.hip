@@ -109,6 +109,21 @@ __device__ __forceinline__ float max16_chain(float t, const f32x16& a) {
   return d;
 }
 
+// Packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two floats per issue slot) and the packed
+// conversion (one v_cvt_pk_bf16_f32 per pair; element-wise casts into a bf16 vector cost a conversion AND a v_perm each).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ bf16x8 pack8(const float* e) {
+  union {
+    bf16x8 v;
+    bf16x2 h[4];
+  } u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) u.h[j] = __builtin_convertvector((f32x2){e[2 * j], e[2 * j + 1]}, bf16x2);
+  return u.v;
+}
+
 // A/B fragment of a 32x32x16 MFMA read by rows: lane (r, hh) gets tile[row0 + r][16*st + 8*hh .. +7]
 __device__ __forceinline__ bf16x8 row_frag(const char* tile, int row0, int st, int r, int hh) {
   return *(const bf16x8*)(tile + tile_off(row0 + r, 16 * st + 8 * hh));
@@ -175,7 +190,7 @@ __device__ __forceinline__ AttnBlock attn_block() {
 
 // ------------------------------------------------------------------ forward
 template <bool HAS_MASK, bool DROPOUT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGEB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -245,15 +260,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     const float alpha = __builtin_amdgcn_exp2f(m - m_new);
     m = m_new;
     const float negm = -m_new;
-    float rs = 0.f;
+    f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][i], sc2, negm));
-        s[sub][i] = e;
-        rs += e;
+      for (int i = 0; i < 16; i += 2) {
+        const f32x2 a = pk_fma((f32x2){s[sub][i], s[sub][i + 1]}, (f32x2){sc2, sc2}, (f32x2){negm, negm});
+        const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        s[sub][i] = e[0];
+        s[sub][i + 1] = e[1];
+        rs2 += e;
       }
+    float rs = rs2[0] + rs2[1];
     rs += __shfl_xor(rs, 32, 64);
     l = l * alpha + rs;
     if (!__all(alpha == 1.f)) {
@@ -269,16 +287,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 pf;
+        float e[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float e = s[sub][8 * ks + j];
+          e[j] = s[sub][8 * ks + j];
           if (DROPOUT) {
             const uint32_t cj = (uint32_t)(sub * 32 + 16 * ks + 8 * (j >> 2) + (j & 3)) * STONK_G_COL;
-            e = stonk_keep_key(rk, ckt + cj, p.drop_thr32) ? e : 0.f;
+            e[j] = stonk_keep_key(rk, ckt + cj, p.drop_thr32) ? e[j] : 0.f;
           }
-          pf[j] = (bf16)e;
         }
+        const bf16x8 pf = pack8(e);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(tr_frag(Vs, sub * 32 + 16 * ks, dt * 32, lane), pf, o[dt]);
       }
@@ -385,20 +403,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
         dp = mfma32(row_frag(Vs, sub * 32, st, r, hh), dof[st], dp);   // dP^T[k][q] = sum_d V[k][d] dO[q][d]
       }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sc2, nlse2));
-        float dpv = dp[i];
+      for (int i = 0; i < 16; i += 2) {
+        const f32x2 a = pk_fma((f32x2){s[i], s[i + 1]}, (f32x2){sc2, sc2}, (f32x2){nlse2, nlse2});
+        const f32x2 pr = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        f32x2 dpv = {dp[i], dp[i + 1]};
         if (DROPOUT) {
-          const uint32_t cj = (uint32_t)(sub * 32 + 8 * (i >> 2) + (i & 3)) * STONK_G_COL;
-          dpv = stonk_keep_key(rk, ckt + cj, p.drop_thr32) ? dpv : 0.f;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const uint32_t cj = (uint32_t)(sub * 32 + 8 * ((i + u) >> 2) + ((i + u) & 3)) * STONK_G_COL;
+            dpv[u] = stonk_keep_key(rk, ckt + cj, p.drop_thr32) ? dpv[u] : 0.f;
+          }
         }
-        s[i] = pr * (dpv - dlt_s);  // dS^T (up to the folded 1/(1-p))
+        const f32x2 ds = pr * (dpv - (f32x2){dlt_s, dlt_s});  // dS^T (up to the folded 1/(1-p))
+        s[i] = ds[0];
+        s[i + 1] = ds[1];
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 dsf;
+        float e[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dsf[j] = (bf16)s[8 * ks + j];
+        for (int j = 0; j < 8; ++j) e[j] = s[8 * ks + j];
+        const bf16x8 dsf = pack8(e);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tr_frag(Ks, sub * 32 + 16 * ks, dt * 32, lane), dsf, dq[dt]);
       }
@@ -456,18 +481,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   const float inv_ds = DROPOUT ? 1.f / p.drop_scale : 1.f;
 
   Stage2 sq, sd;
+  // row statistics of a tile: threads 0..63 carry -lse (log2 units), 64..127 -(1-p) * delta. The loaded word is only
+  // touched when the tile is stored (arithmetic at the load would wait for it, and for the tile loads issued before it,
+  // at the top of every iteration).
   float sreg = 0.f;
+  const float* sptr = tid < TK ? p.lse + statbase + tid : p.delta + statbase + tid - TK;
+  const float sfac = tid < TK ? -LOG2E : -inv_ds;
   auto load_tile = [&](int qt) {
     stage_load(sq, qbase + (long)qt * TK * p.ld, p.ld, tid);
     stage_load(sd, dbase + (long)qt * TK * p.lddo, p.lddo, tid);
-    if (tid < TK) sreg = -p.lse[statbase + qt * TK + tid] * LOG2E;            // -lse in log2 units
-    else if (tid < 2 * TK) sreg = p.delta[statbase + qt * TK + tid - TK] * inv_ds;  // (1-p) * delta
+    if (tid < 2 * TK) sreg = sptr[qt * TK];
   };
   auto store_tile = [&](int buf) {
     char* base = lds + buf * STAGEB;
     stage_store(sq, base, tid);
     stage_store(sd, base + TILEB, tid);
-    if (tid < 2 * TK) ((float*)(base + 2 * TILEB))[tid] = sreg;
+    if (tid < 2 * TK) ((float*)(base + 2 * TILEB))[tid] = sreg * sfac;
   };
   load_tile(0);
   store_tile(0);
@@ -496,30 +525,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 nls = *(const f32x4*)(Ls + sub * 32 + 8 * g + 4 * hh);
-        const f32x4 dl = *(const f32x4*)(Dl + sub * 32 + 8 * g + 4 * hh);
+        const f32x4 dl = *(const f32x4*)(Dl + sub * 32 + 8 * g + 4 * hh);   // -(1-p) * delta
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; j += 2) {
           const int i = 4 * g + j;
-          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sc2, nls[j]));
-          float pd = pr, dpv = dp[i];
+          const f32x2 a = pk_fma((f32x2){s[i], s[i + 1]}, (f32x2){sc2, sc2}, (f32x2){nls[j], nls[j + 1]});
+          const f32x2 pr = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+          f32x2 pd = pr;
           if (DROPOUT) {
-            const uint32_t rj = (uint32_t)(sub * 32 + 8 * g + j) * STONK_G_ROW;
-            const bool keep = stonk_keep_key(rkt + rj, ck, p.drop_thr32);
-            pd = keep ? pr : 0.f;
-            dpv = keep ? dpv : 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const uint32_t rj = (uint32_t)(sub * 32 + 8 * g + j + u) * STONK_G_ROW;
+              pd[u] = stonk_keep_key(rkt + rj, ck, p.drop_thr32) ? pr[u] : 0.f;
+            }
           }
-          s[i] = pd;                       // dropped P (feeds dV), up to the folded 1/(1-p)
-          dp[i] = pr * (dpv - dl[j]);      // dS (feeds dK), up to the folded 1/(1-p)
+          // dS = P (drop(dP) - delta) = dropped P . dP + P . (-delta): one select per score instead of two
+          const f32x2 ds = pk_fma(pd, (f32x2){dp[i], dp[i + 1]}, pr * (f32x2){dl[j], dl[j + 1]});
+          s[i] = pd[0];                    // dropped P (feeds dV), up to the folded 1/(1-p)
+          s[i + 1] = pd[1];
+          dp[i] = ds[0];                   // dS (feeds dK), up to the folded 1/(1-p)
+          dp[i + 1] = ds[1];
         }
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 pf, dsf;
+        float e[8], f[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          pf[j] = (bf16)s[8 * ks + j];
-          dsf[j] = (bf16)dp[8 * ks + j];
+          e[j] = s[8 * ks + j];
+          f[j] = dp[8 * ks + j];
         }
+        const bf16x8 pf = pack8(e), dsf = pack8(f);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           dv[dt] = mfma32(tr_frag(Ds, sub * 32 + 16 * ks, dt * 32, lane), pf, dv[dt]);   // dV^T += dO^T . P

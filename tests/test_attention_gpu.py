@@ -126,6 +126,47 @@ def test_attention_dropout_statistics_and_replay(hip):
     assert _relerr(accv / n, g_ref[:, 2 * H:]) < 0.1
 
 
+def test_attention_backward_replays_the_forward_mask_exactly(hip):
+    """The dropout mask is regenerated by three kernels with different lane layouts (query on the lane in the forward and
+    the dQ kernel, key on the lane in dK/dV). Recover the forward's mask element by element - 64 valid keys per sequence,
+    spread over every key tile and both parities, with one-hot V rows: out[q][j] = P[q][key_j] keep[q][key_j] / (1 - p) -
+    and check dQ, dK and dV against a torch backward through THAT mask."""
+    B, S, NH, p, seed = 2, 256, 2, 0.25, 77
+    H = NH * 64
+    qkv, dout, _ = _inputs(B, S, NH, 31, False)
+    keys = torch.tensor(sorted({4 * i + (i % 4) for i in range(64)}), device="cuda")
+    assert keys.numel() == 64 and len({int(k) // 64 for k in keys}) == 4 and len({int(k) % 2 for k in keys}) == 2
+    mask = torch.zeros(B, S, dtype=torch.long, device="cuda")
+    mask[:, keys] = 1
+    v = qkv.view(B, S, 3, NH, 64)
+    v[:, keys, 2] = torch.eye(64, device="cuda", dtype=torch.bfloat16)[None, :, None, :].expand(B, 64, NH, 64)
+    out, lse = _run_fwd(hip, qkv, mask, B, S, NH, p, seed)
+    x = qkv.float().view(B, S, 3, NH, 64).permute(2, 0, 3, 1, 4).contiguous()   # [3,B,NH,S,64]
+    q, k, vv = x[0], x[1], x[2]
+    sc = q @ k.transpose(-1, -2) / 8.0 + (1.0 - mask.float())[:, None, None, :] * torch.finfo(torch.float32).min
+    P = torch.softmax(sc, -1)                                                    # [B,NH,S,S], zero on masked keys
+    o = out.float().view(B, S, NH, 64).permute(0, 2, 1, 3)                       # [B,NH,S,64] = P[..., keys] * keep / (1-p)
+    keep_valid = o != 0
+    rate = keep_valid.float().mean().item()
+    assert abs(rate - (1 - p)) < 0.01, rate
+    torch.testing.assert_close(o, P[..., keys] * keep_valid / (1 - p), rtol=2e-2, atol=2e-3)
+    keep = torch.zeros(B, NH, S, S, device="cuda")
+    keep[..., keys] = keep_valid.float()
+    # backward through the recovered mask
+    dO = dout.float().view(B, S, NH, 64).permute(0, 2, 1, 3)
+    Pd = P * keep / (1 - p)
+    dV = Pd.transpose(-1, -2) @ dO
+    dP = (dO @ vv.transpose(-1, -2)) * keep / (1 - p)
+    dS = P * (dP - (dP * P).sum(-1, keepdim=True))
+    dQ = dS @ k / 8.0
+    dK = dS.transpose(-1, -2) @ q / 8.0
+    ref = torch.stack([dQ, dK, dV]).permute(1, 3, 0, 2, 4).reshape(B * S, 3 * H)
+    dqkv = _run_bwd(hip, qkv, mask, out, dout, lse, B, S, NH, p, seed)
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        e = _relerr(dqkv[:, sl], ref[:, sl])
+        assert e < 2e-2, (name, e)   # (a kernel replaying a different mask is off by order 1)
+
+
 def test_attention_bad_shape(hip):
     qkv = torch.zeros(100, 192, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(hip.StonkHipError):

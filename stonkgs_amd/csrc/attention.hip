@@ -163,9 +163,10 @@ __device__ __forceinline__ void stage_store(const Stage2& s, char* tile, int tid
 // Every kernel below runs the same pipeline: tile t+1 is fetched into registers while tile t is computed from LDS
 // stage t&1, written to the other stage when the compute is done, ONE barrier per tile.
 //
-// Dropout: element (query row, key) is kept iff stonk_keep_key(rowkey(flat (b,h,q)), colkey(key)); both keys are
-// linear, so the kernel with the query on the lane adds a compile-time constant to the tile's column key per element
-// and the kernel with the key on the lane does the same with the row key. The 1/(1-p) factor never touches an
+// Dropout: element (query row, key) is kept iff stonk_pair_keep(stonk_pair_round1(rowkey(flat (b,h,q)), colkey(key >> 1)),
+// key odd ? C2_ODD : C2_EVEN) - one first hash round per PAIR of keys (common.h). Both keys are linear, so the kernels with
+// the query on the lane add a compile-time constant to the tile's pair key per two elements and the kernel with the key
+// on the lane does the same with the row key per element. The 1/(1-p) factor never touches an
 // element: it is folded into the output normalisation (forward, dV) or into delta and the final scale (dQ, dK).
 
 // Workgroup -> (128-row block, head, sequence). Workgroups are dispatched round-robin over the 8 XCDs in linear order, so
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
   const bf16* vbase = p.v + tok0 * p.ld + h * HD;
   const int ntiles = S / TK;
   const uint32_t rk = stonk_rowkey((uint32_t)((b * p.NH + h) * S + q0 + r), p.seed);
-  const uint32_t ck_lane = stonk_colkey((uint32_t)(4 * hh));
+  const uint32_t ck_lane = stonk_colkey((uint32_t)(2 * hh));   // key PAIRS: this lane's keys start at 4 hh = pair 2 hh
 
   Stage2 sk, sv;
   long mreg = 1;
@@ -282,18 +283,21 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
       }
     }
     // O^T += V^T . P^T
-    const uint32_t ckt = ck_lane + (uint32_t)(kt * TK) * STONK_G_COL;
+    const uint32_t ckt = ck_lane + (uint32_t)(kt * TK / 2) * STONK_G_COL;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         float e[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 8; j += 2) {   // elements j, j + 1 are keys 2m, 2m + 1 of one pair
           e[j] = s[sub][8 * ks + j];
+          e[j + 1] = s[sub][8 * ks + j + 1];
           if (DROPOUT) {
-            const uint32_t cj = (uint32_t)(sub * 32 + 16 * ks + 8 * (j >> 2) + (j & 3)) * STONK_G_COL;
-            e[j] = stonk_keep_key(rk, ckt + cj, p.drop_thr32) ? e[j] : 0.f;
+            const uint32_t cj = (uint32_t)((sub * 32 + 16 * ks + 8 * (j >> 2) + (j & 3)) >> 1) * STONK_G_COL;
+            const uint32_t y8 = stonk_pair_round1(rk, ckt + cj);
+            e[j] = stonk_pair_keep(y8, STONK_C2_EVEN, p.drop_thr32) ? e[j] : 0.f;
+            e[j + 1] = stonk_pair_keep(y8, STONK_C2_ODD, p.drop_thr32) ? e[j + 1] : 0.f;
           }
         }
         const bf16x8 pf = pack8(e);
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const bf16* vbase = p.v + tok0 * p.ld + h * HD;
   const int ntiles = S / TK;
   const uint32_t rk = stonk_rowkey((uint32_t)stat, p.seed);
-  const uint32_t ck_lane = stonk_colkey((uint32_t)(4 * hh));
+  const uint32_t ck_lane = stonk_colkey((uint32_t)(2 * hh));   // key pairs, as in the forward
 
   Stage2 sk, sv;
   long mreg = 1;
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     const char* Vs = Ks + TILEB;
     const float* Mb = (const float*)(Ks + 2 * TILEB);
     if (kt + 1 < ntiles) load_tile(kt + 1);
-    const uint32_t ckt = ck_lane + (uint32_t)(kt * TK) * STONK_G_COL;
+    const uint32_t ckt = ck_lane + (uint32_t)(kt * TK / 2) * STONK_G_COL;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;
@@ -408,11 +412,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
         const f32x2 pr = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
         f32x2 dpv = {dp[i], dp[i + 1]};
         if (DROPOUT) {
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const uint32_t cj = (uint32_t)(sub * 32 + 8 * ((i + u) >> 2) + ((i + u) & 3)) * STONK_G_COL;
-            dpv[u] = stonk_keep_key(rk, ckt + cj, p.drop_thr32) ? dpv[u] : 0.f;
-          }
+          const uint32_t cj = (uint32_t)((sub * 32 + 8 * (i >> 2) + (i & 3)) >> 1) * STONK_G_COL;
+          const uint32_t y8 = stonk_pair_round1(rk, ckt + cj);
+          dpv[0] = stonk_pair_keep(y8, STONK_C2_EVEN, p.drop_thr32) ? dpv[0] : 0.f;
+          dpv[1] = stonk_pair_keep(y8, STONK_C2_ODD, p.drop_thr32) ? dpv[1] : 0.f;
         }
         const f32x2 ds = pr * (dpv - (f32x2){dlt_s, dlt_s});  // dS^T (up to the folded 1/(1-p))
         s[i] = ds[0];
@@ -477,7 +480,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   const long statbase = (long)(b * p.NH + h) * S;
   const int ntiles = S / TK;
   const uint32_t rk_lane = stonk_rowkey((uint32_t)(statbase + 4 * hh), p.seed);
-  const uint32_t ck = stonk_colkey((uint32_t)(k0 + r));
+  const uint32_t ck = stonk_colkey((uint32_t)((k0 + r) >> 1));                   // this lane's key: its pair ...
+  const uint32_t c2 = ((k0 + r) & 1) ? STONK_C2_ODD : STONK_C2_EVEN;              // ... and its half of it
   const float inv_ds = DROPOUT ? 1.f / p.drop_scale : 1.f;
 
   Stage2 sq, sd;
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
               const uint32_t rj = (uint32_t)(sub * 32 + 8 * g + j + u) * STONK_G_ROW;
-              pd[u] = stonk_keep_key(rkt + rj, ck, p.drop_thr32) ? pr[u] : 0.f;
+              pd[u] = stonk_pair_keep(stonk_pair_round1(rkt + rj, ck), c2, p.drop_thr32) ? pr[u] : 0.f;
             }
           }
           // dS = P (drop(dP) - delta) = dropped P . dP + P . (-delta): one select per score instead of two

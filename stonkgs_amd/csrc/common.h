@@ -100,6 +100,18 @@ __device__ __forceinline__ bool stonk_keep_key(uint32_t rowkey, uint32_t colkey,
   const uint32_t y = __umul24(x, 0xB5297Bu) + x;
   return __umul24(y >> 8, 0x68E31Du) >= thr32;
 }
+// The same generator for a PAIR of neighbouring columns (2j, 2j+1) - the attention probabilities' dropout: the first
+// round is computed once per pair from the pair's key (colkey(j)), the last round twice with different multipliers; the
+// even column's decision is stonk_keep_key(rowkey, colkey(j)). A lane that walks the keys of one query (forward, dQ) pays
+// 5 VALU operations per score instead of 7; a lane that owns one key (dK/dV) keeps its multiplier in a register and pays
+// what it paid. Keep rate, row / column sums and the joint drop rates inside a pair, across pairs, along rows, columns
+// and 2x2 minors are those of independent draws (checked offline as above).
+constexpr uint32_t STONK_C2_EVEN = 0x68E31Du, STONK_C2_ODD = 0x9E3779u;
+__device__ __forceinline__ uint32_t stonk_pair_round1(uint32_t rowkey, uint32_t pairkey) {
+  const uint32_t x = rowkey ^ pairkey;
+  return (__umul24(x, 0xB5297Bu) + x) >> 8;
+}
+__device__ __forceinline__ bool stonk_pair_keep(uint32_t y8, uint32_t c2, uint32_t thr32) { return __umul24(y8, c2) >= thr32; }
 __device__ __forceinline__ bool stonk_keep(uint32_t row, uint32_t col, uint32_t seedmix, uint32_t thr32) {
   return stonk_keep_key(stonk_rowkey(row, seedmix), stonk_colkey(col), thr32);
 }

@@ -25,6 +25,11 @@
 #define STONK_GEMM_WAVE4 3    /* persistent 256x256x64, four waves with 128x128 wave tiles (gemm_w4.hip) */
 #define STONK_GEMM_WAVE4_192 4 /* the same kernel on 256x192 tiles (128x96 wave tiles): N % 192 == 0, bf16 output, the \
                                  epilogues of the N = 768 launches (none, bias, residual, bias + residual [+ dropout]) */
+#define STONK_GEMM_DISPATCHED 5 /* the launcher's choice as with AUTO, launched so that the hardware dispatcher hands out the \
+                                 work: the four-wave kernel with ONE work item per workgroup (grid = tiles; 2-8 % slower alone - no \
+                                 prefetch across tile boundaries), 128x128 tiles where AUTO would take the eight-wave kernel. For a \
+                                 launch beside which another stream (a collective) holds CUs: a persistent grid with a static tile \
+                                 split waits for its last workgroup to get a CU */
 // --- stonk_layernorm_* `flags` ---
 #define STONK_LN_DROPOUT (1 << 0)
 // --- stonk_small_linear_* `act` ---

@@ -200,6 +200,29 @@ def test_gemm_device_row_count_and_dropout(hip):
     assert torch.equal(out, out2)  # same (seed, index) -> same mask, bit for bit
 
 
+@pytest.mark.parametrize("M,N,K,fl", [(4096, 768, 768, 0), (2048, 768, 3072, "resid"), (2048, 3072, 768, "gelu_bwd"), (1024, 2304, 768, "bias"),
+                                      (1024, 1536, 768, 0), (300, 768, 768, 0)])
+def test_gemm_dispatched_is_auto_without_a_persistent_grid(hip, M, N, K, fl):
+    """STONK_GEMM_DISPATCHED: the launcher's own choice, one work item per workgroup (the form for launches beside a
+    collective). Same kernel, same tiles, same arithmetic: bit-identical to AUTO - also where AUTO takes the eight-wave
+    kernel (wide plain launches; DISPATCHED then uses the 128x128 one: equal within rounding) or 128x128 tiles anyway."""
+    A, B = _rand((M, K), 1.0, 61), _rand((N, K), 0.05, 62)
+    kw = {}
+    flags = 0
+    if fl == "resid":
+        flags, kw = hip.EPI_RESID, {"resid": _rand((M, N), 1.0, 63)}
+    elif fl == "gelu_bwd":
+        flags, kw = hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD, {"aux": _rand((M, N), 1.0, 64)}
+    elif fl == "bias":
+        flags, kw = hip.EPI_BIAS, {"bias": torch.randn(N, device="cuda")}
+    auto = _gemm(hip, A, B, flags=flags, kernel=hip.GEMM_AUTO, **kw)
+    disp = _gemm(hip, A, B, flags=flags, kernel=hip.GEMM_DISPATCHED, **kw)
+    if N == 1536:
+        torch.testing.assert_close(disp.float(), auto.float(), rtol=2e-2, atol=2e-2)
+    else:
+        assert torch.equal(auto, disp)
+
+
 def test_gemm_bad_arguments(hip):
     A, B = _rand((128, 64)), _rand((100, 64))
     with pytest.raises(hip.StonkHipError):

@@ -22,6 +22,7 @@ traffic = list(csv.reader(open(os.path.join(R, "r02_pmc_traffic.csv"))))
 tn = next(r for r in traffic if r[0].startswith("gemm_tn_w4"))
 mf = list(csv.reader(open(os.path.join(R, "r02_pmc_mfma.csv"))))
 mf_total = float(mf[-1][4])
+c4tn = float(next(r for r in csv.DictReader(open(os.path.join(R, "r02_c4_24L1024_kernel_stats.csv"))) if "gemm_tn_w4" in r["Name"])["Percentage"])
 mfc4 = float(list(csv.reader(open(os.path.join(R, "r02_c4_24L1024_pmc_mfma.csv"))))[-1][4])
 avg = float(rows[0]["AverageNs"]) / 1e3
 rf, ru = d["roofline"], up["roofline"]
@@ -38,10 +39,13 @@ sec = f'''# profiles — round 2 (MI355X, gfx950, ROCm 7.2, one GPU)
 
 ## Headline (round 2)
 
-* **{d["value"]:.0f} text-triple pairs/s, {d["ms_per_step"]:.2f} ms per step** (`r02_final_bench.json`); commits of this round read between 34.85 and
+* **{d["value"]:.0f} text-triple pairs/s, {d["ms_per_step"]:.2f} ms per step** (`r02_final_bench.json`); commits of this round read between 34.4 and
   37.34 ms on different boxes of the pool - a 7 % spread, larger than most single changes - so every comparison below is an
-  interleaved A/B inside one process (`tools/ab_step.py`). Round 2's kernel routing against round 1's on one box:
-  **36.10 -> 35.46 ms**.
+  interleaved A/B inside one process (`tools/ab_step.py`) or, for a change inside the library, the two builds run in turn
+  on one box. Round 2's kernel routing against round 1's on one box: **36.10 -> 35.46 ms**; the attention kernels' VALU diet
+  (packed fp32 math and conversions, one select per score and no wait on the statistics load in dK/dV, one first hash round
+  per pair of keys) took another 0.6 ms: forward 128 -> 112 us, dQ 161 -> 144, dK/dV 217 -> 197 per layer alone
+  (`tools/prof_attention.sh`), 589 -> 522 us per layer in the step's profile.
 * `roofline` (dominant kernel `gemm_tn_w4_kernel`, {rf["launches_per_step"]} launches per step, {rf["avg_launch_gflop"]:.1f} GFLOP each on average): **{rf["frac"]:.3f} of the
   2.5 PFLOP/s peak as the step runs it** ({rf["avg_launch_us"]:.0f} us per launch by HIP events on the second stream; the rocprofv3 summary of the
   profiled run says {avg:.0f} us -> {ru["avg_launch_gflop"] / avg / 2.5:.3f}, and that run printed {ru["frac"]:.3f}) and {al["alone"]["frac"]:.3f} for the same launches alone
@@ -59,7 +63,7 @@ sec = f'''# profiles — round 2 (MI355X, gfx950, ROCm 7.2, one GPU)
   float atomics per launch.
 * CPU baseline (the oracle, fp32, same model shape, batch 8): {d["cpu_baseline"]["value"]:.2f} pairs/s on the box's {d["cpu_baseline"]["cores"]} host threads, {d["cpu_baseline"]["at_8_threads"]["value"]:.2f} at 8.
 * config 4 (24L / 1024h, batch 64, `r02_c4_24L1024_bench.json`, under rocprofv3): {c4["value"]:.0f} pairs/s, {c4["ms_per_step"]:.1f} ms per step,
-  1217 GFLOP per pair -> `step_mfma_frac` {c4["step_mfma_frac"]:.3f}; `gemm_tn_w4_kernel` is 27 % of its GPU time.
+  1217 GFLOP per pair -> `step_mfma_frac` {c4["step_mfma_frac"]:.3f}; `gemm_tn_w4_kernel` is {c4tn:.0f} % of its GPU time.
 
 ## Where the step goes (r02_kernel_stats.csv, per step; total kernel time {tot:.1f} ms against {up["ms_per_step"]:.1f} ms wall: three streams overlap)
 

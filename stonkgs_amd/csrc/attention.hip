@@ -174,19 +174,65 @@ __device__ __forceinline__ void stage_store(const Stage2& s, char* tile, int tid
 // different XCDs and each L2 fetches the head again: 455 MB of fabric reads per forward launch against 151 MB of Q/K/V
 // (rocprofv3 FETCH_SIZE). Here every XCD takes one contiguous run of the linear (sequence, head, block) order, so a
 // head's blocks share an L2 and run at the same time.
+//
+// Which (sequence, head) pairs an XCD gets matters as well once fully masked key tiles are skipped: sequences differ in
+// length, and a contiguous run of sequences per XCD leaves the XCD with the longest ones working alone at the end (a batch
+// sorted by length: no gain from the skipping at all). When the pairs divide by 8, XCD x takes pairs x, x + 8, ... - one
+// or two heads of EVERY sequence.
 struct AttnBlock { int xb, h, b; };
 __device__ __forceinline__ AttnBlock attn_block() {
   const int nx = gridDim.x, nh = gridDim.y;
   const int n = nx * nh * gridDim.z;
   const int lin = blockIdx.x + nx * (blockIdx.y + nh * blockIdx.z);
   const int q = n >> 3, rm = n & 7, x = lin & 7;
-  const int l = ((x < rm) ? x * (q + 1) : rm * (q + 1) + (x - rm) * q) + (lin >> 3);
+  int l = ((x < rm) ? x * (q + 1) : rm * (q + 1) + (x - rm) * q) + (lin >> 3);
+  if (((nh * gridDim.z) & 7) == 0) {
+    const int j = lin >> 3;
+    l = ((j / nx) * 8 + x) * nx + j % nx;
+  }
   AttnBlock o;
   o.xb = l % nx;
   const int t = l / nx;
   o.h = t % nh;
   o.b = t / nh;
   return o;
+}
+
+// Key tiles (64 keys) of a sequence that hold at least one unmasked key, one bit per tile: a fully masked tile adds
+// exactly nothing to any query (its scores are -2^100 in raw units, their exp2 is 0), so the kernels with the keys in the
+// tile loop walk the set bits only - in the STonKGs layout the padding of the text half, 112 of 512 positions on average
+// in the benchmark's batches. In two halves, so that the mask words travel while the kernel's other first loads do (asked
+// for first, they are also the first to arrive): live_issue() requests them, live_finish() returns the bits - 0 when NO
+// key of the sequence is unmasked (the reference then attends uniformly: the callers walk every tile), all ones without a
+// mask or beyond 1024 keys. live_finish() contains two barriers.
+struct LiveTiles {
+  long mv[4];
+};
+template <bool HAS_MASK>
+__device__ __forceinline__ void live_issue(LiveTiles& t, const long* mask, long tok0, int S, int tid) {
+  if (!HAS_MASK || S > 1024) return;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int key = c * 256 + tid;   // the 64 lanes of a wave look at one tile
+    t.mv[c] = key < S ? mask[tok0 + key] : 0;
+  }
+}
+template <bool HAS_MASK>
+__device__ __forceinline__ uint64_t live_finish(const LiveTiles& t, int S, int tid) {
+  const int nt = S / TK;
+  const uint64_t all = nt >= 64 ? ~0ull : ((1ull << nt) - 1);
+  if (!HAS_MASK || S > 1024) return all;
+  __shared__ int tile_live[16];
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint64_t b = __ballot(t.mv[c] != 0);
+    if (lane == 0) tile_live[c * 4 + wave] = b != 0;
+  }
+  __syncthreads();
+  const uint64_t m = __ballot(lane < nt && tile_live[lane & 15] != 0);
+  __syncthreads();
+  return m;
 }
 
 // ------------------------------------------------------------------ forward
@@ -201,6 +247,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
   const int q0 = blk.xb * 128 + wave * 32;
   const long tok0 = (long)b * S;
   const float sc2 = p.scale * LOG2E;
+  LiveTiles lt;
+  live_issue<HAS_MASK>(lt, p.mask, tok0, S, tid);
 
   bf16x8 qf[4];
   {
@@ -232,15 +280,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
     stage_store(sv, base + TILEB, tid);
     if (HAS_MASK && tid < TK) ((float*)(base + 2 * TILEB))[tid] = mreg != 0 ? 0.f : NEG_MASK;
   };
-  load_tile(0);
+  load_tile(0);   // (before the live bits are known: tile 0 almost always is - [CLS])
+  uint64_t rem = live_finish<HAS_MASK>(lt, S, tid);
+  if (rem == 0) rem = ntiles >= 64 ? ~0ull : ((1ull << ntiles) - 1);
+  int kt = __builtin_ctzll(rem);
+  rem &= rem - 1;
+  if (kt != 0) load_tile(kt);
   store_tile(0);
   __syncthreads();
 
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const char* Ks = lds + (kt & 1) * STAGEB;
+  for (int it = 0;; ++it) {   // the live key tiles, in order
+    const char* Ks = lds + (it & 1) * STAGEB;
     const char* Vs = Ks + TILEB;
     const float* Mb = (const float*)(Ks + 2 * TILEB);
-    if (kt + 1 < ntiles) load_tile(kt + 1);
+    const int nx = rem ? __builtin_ctzll(rem) : -1;
+    rem &= rem - 1;
+    if (nx >= 0) load_tile(nx);
     // S^T = K . Q^T (+ key bias through the accumulator) for the two 32-key halves of the tile, raw units
     f32x16 s[2];
 #pragma unroll
@@ -304,8 +359,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(tr_frag(Vs, sub * 32 + 16 * ks, dt * 32, lane), pf, o[dt]);
       }
-    if (kt + 1 < ntiles) store_tile((kt + 1) & 1);
+    if (nx >= 0) store_tile((it + 1) & 1);
     __syncthreads();
+    if (nx < 0) break;
+    kt = nx;
   }
   const float inv = (DROPOUT ? p.drop_scale : 1.f) / l;
   bf16* orow = p.out + (tok0 + q0 + r) * p.ldo + h * HD;
@@ -332,7 +389,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const int S = p.S;
   const int q0 = blk.xb * 128 + wave * 32;
   const long tok0 = (long)b * S;
-  const float sc2 = p.scale * LOG2E;
+  LiveTiles lt;
+  live_issue<HAS_MASK>(lt, p.mask, tok0, S, tid);
 
   bf16x8 qf[4], dof[4];
   float dlt = 0.f;
@@ -352,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   dlt += __shfl_xor(dlt, 32, 64);
   const long stat = (long)(b * p.NH + h) * S + q0 + r;
   if (hh == 0) p.delta[stat] = dlt;
-  const float nlse2 = -p.lse[stat] * LOG2E;
+  const float lse_q = p.lse[stat];
   // dS = P * (drop(dP) - delta) with drop(dP) = keep ? dP / (1-p) : 0  ==  (1/(1-p)) * P * ((keep ? dP : 0) - (1-p) delta)
   const float dlt_s = DROPOUT ? dlt / p.drop_scale : dlt;
   f32x16 dq[2];
@@ -378,15 +436,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     stage_store(sv, base + TILEB, tid);
     if (HAS_MASK && tid < TK) ((float*)(base + 2 * TILEB))[tid] = mreg != 0 ? 0.f : NEG_MASK;
   };
-  load_tile(0);
+  load_tile(0);   // (before the live bits are known)
+  uint64_t rem = live_finish<HAS_MASK>(lt, S, tid);
+  // No unmasked key in the whole sequence: the reference's finfo.min absorbs every score and it attends uniformly, P = 1/S.
+  // The forward gets there by the same absorption; its log-sum-exp (-2^100-sized) cannot carry log S, so the backward
+  // kernels rebuild P from a zero score scale and lse = log S. (Never the case in a STonKGs batch - [CLS] is always live.)
+  const bool uniform = rem == 0;
+  if (uniform) rem = ntiles >= 64 ? ~0ull : ((1ull << ntiles) - 1);
+  const float sc2 = uniform ? 0.f : p.scale * LOG2E;
+  const float nlse2 = uniform ? -__builtin_amdgcn_logf((float)S) : -lse_q * LOG2E;   // (v_log_f32 is log2)
+  int kt = __builtin_ctzll(rem);
+  rem &= rem - 1;
+  if (kt != 0) load_tile(kt);
   store_tile(0);
   __syncthreads();
 
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const char* Ks = lds + (kt & 1) * STAGEB;
+  for (int it = 0;; ++it) {   // the live key tiles, in order (a fully masked tile gives dS = 0)
+    const char* Ks = lds + (it & 1) * STAGEB;
     const char* Vs = Ks + TILEB;
     const float* Mb = (const float*)(Ks + 2 * TILEB);
-    if (kt + 1 < ntiles) load_tile(kt + 1);
+    const int nx = rem ? __builtin_ctzll(rem) : -1;
+    rem &= rem - 1;
+    if (nx >= 0) load_tile(nx);
     const uint32_t ckt = ck_lane + (uint32_t)(kt * TK / 2) * STONK_G_COL;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -431,8 +502,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
         for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tr_frag(Ks, sub * 32 + 16 * ks, dt * 32, lane), dsf, dq[dt]);
       }
     }
-    if (kt + 1 < ntiles) store_tile((kt + 1) & 1);
+    if (nx >= 0) store_tile((it + 1) & 1);
     __syncthreads();
+    if (nx < 0) break;
+    kt = nx;
   }
   const float fs = DROPOUT ? p.scale * p.drop_scale : p.scale;
   bf16* orow = p.dq + (tok0 + q0 + r) * p.ldd + h * HD;
@@ -457,7 +530,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   const int S = p.S;
   const int k0 = blk.xb * 128 + wave * 32;
   const long tok0 = (long)b * S;
-  const float sc2 = p.scale * LOG2E;
+  LiveTiles lt;
+  live_issue<HAS_MASK>(lt, p.mask, tok0, S, tid);
 
   bf16x8 kf[4], vf[4];
   {
@@ -471,6 +545,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   }
   float mb = 0.f;
   if (HAS_MASK) mb = p.mask[tok0 + k0 + r] != 0 ? 0.f : NEG_MASK;
+  // Masked keys get exactly zero gradient (P = 0 for every query), unless NO key of the sequence is unmasked (the reference
+  // then attends uniformly): a wave whose 32 keys are all masked skips its arithmetic - its accumulators stay zero and it
+  // only helps to stage the tiles - and a workgroup whose 128 keys are all masked writes its zeros and leaves.
+  bool uniform = false;   // no unmasked key at all: P = 1/S, see the dQ kernel (set below, once the first loads are under way)
   f32x16 dk[2], dv[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) dk[0][i] = dk[1][i] = dv[0][i] = dv[1][i] = 0.f;
@@ -491,6 +569,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   float sreg = 0.f;
   const float* sptr = tid < TK ? p.lse + statbase + tid : p.delta + statbase + tid - TK;
   const float sfac = tid < TK ? -LOG2E : -inv_ds;
+  const float nlog2s = -__builtin_amdgcn_logf((float)S);
   auto load_tile = [&](int qt) {
     stage_load(sq, qbase + (long)qt * TK * p.ld, p.ld, tid);
     stage_load(sd, dbase + (long)qt * TK * p.lddo, p.lddo, tid);
@@ -500,13 +579,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
     char* base = lds + buf * STAGEB;
     stage_store(sq, base, tid);
     stage_store(sd, base + TILEB, tid);
-    if (tid < 2 * TK) ((float*)(base + 2 * TILEB))[tid] = sreg * sfac;
+    if (tid < 2 * TK) ((float*)(base + 2 * TILEB))[tid] = (uniform && tid < TK) ? nlog2s : sreg * sfac;
   };
-  load_tile(0);
-  store_tile(0);
+  load_tile(0);   // (before the live bits are known; a workgroup that then leaves has asked for one tile in vain)
+  const uint64_t seq = live_finish<HAS_MASK>(lt, S, tid);
+  uniform = seq == 0;
+  const float sc2 = uniform ? 0.f : p.scale * LOG2E;
+  bool wave_live = true, wg_live = true;
+  if (HAS_MASK) {
+    wave_live = uniform || __ballot(mb == 0.f) != 0;
+    wg_live = uniform || ((seq >> (2 * blk.xb)) & 3) != 0;
+  }
+  if (wg_live) store_tile(0);
   __syncthreads();
 
-  for (int qt = 0; qt < ntiles; ++qt) {
+  for (int qt = 0; qt < (wg_live ? ntiles : 0); ++qt) {
     const char* Qs = lds + (qt & 1) * STAGEB;
     const char* Ds = Qs + TILEB;
     const float* Ls = (const float*)(Qs + 2 * TILEB);
@@ -515,6 +602,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
     const uint32_t rkt = rk_lane + (uint32_t)(qt * TK) * STONK_G_ROW;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      if (!wave_live) break;
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {

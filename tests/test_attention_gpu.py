@@ -83,6 +83,34 @@ def test_attention_fwd_bwd(hip, B, S, NH, masked):
     assert torch.equal(dqkv, dqkv2)
 
 
+def test_attention_skips_masked_key_tiles_exactly(hip):
+    """Key tiles without an unmasked key are not visited (forward, dQ), workgroups / waves whose keys are all masked leave
+    early (dK/dV): results must not change - including the degenerate sequence with NO unmasked key, where the reference
+    attends uniformly and every key gets gradient, and a sequence whose only live tiles are the first and the last."""
+    B, S, NH = 4, 512, 2
+    qkv, dout, _ = _inputs(B, S, NH, 77, False)
+    mask = torch.ones(B, S, dtype=torch.long, device="cuda")
+    mask[0, 40:256] = 0          # tiles 1-3 dead, the 128-key block 1 entirely
+    mask[1, :] = 0               # nothing unmasked
+    mask[2, 1:448] = 0           # [CLS] and the last tile only
+    mask[3, 100:130] = 0         # no dead tile at all
+    o_ref, lse_ref, g_ref = _ref(qkv, mask, B, S, NH, dout)
+    out, lse = _run_fwd(hip, qkv, mask, B, S, NH)
+    torch.testing.assert_close(out.float(), o_ref, rtol=2e-2, atol=2e-2)
+    live = [0, 2, 3]             # (the log-sum-exp of the all-masked row is finfo.min-sized in the reference)
+    torch.testing.assert_close(lse[live], lse_ref[live], rtol=1e-4, atol=2e-3)
+    dqkv = _run_bwd(hip, qkv, mask, out, dout, lse, B, S, NH)
+    H = NH * 64
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        for b in range(B):
+            rows = slice(b * S, (b + 1) * S)
+            e = _relerr(dqkv[rows, sl], g_ref[rows, sl])
+            assert e < 2e-2, (name, b, e)
+    # masked keys of a sequence that has live ones: exactly zero gradient
+    dead = (mask[0] == 0).nonzero().flatten()
+    assert float(dqkv[dead][:, H:].abs().max()) == 0.0
+
+
 def test_attention_spike_forces_online_rescale(hip):
     """One key per tile dominates a query: exercises the running-max rescale branch (guide rule 26)."""
     B, S, NH = 1, 256, 1

@@ -45,7 +45,9 @@ sec = f'''# profiles — round 2 (MI355X, gfx950, ROCm 7.2, one GPU)
   on one box. Round 2's kernel routing against round 1's on one box: **36.10 -> 35.46 ms**; the attention kernels' VALU diet
   (packed fp32 math and conversions, one select per score and no wait on the statistics load in dK/dV, one first hash round
   per pair of keys) took another 0.6 ms: forward 128 -> 112 us, dQ 161 -> 144, dK/dV 217 -> 197 per layer alone
-  (`tools/prof_attention.sh`), 589 -> 522 us per layer in the step's profile.
+  (`tools/prof_attention.sh`), 589 -> 522 us per layer in the step's profile; not visiting fully masked key tiles (the padding of
+  the text half: 1.3 of 8 tiles per sequence in these batches) and dealing (sequence, head) pairs round-robin to the XCDs:
+  34.3 -> 33.9 ms.
 * `roofline` (dominant kernel `gemm_tn_w4_kernel`, {rf["launches_per_step"]} launches per step, {rf["avg_launch_gflop"]:.1f} GFLOP each on average): **{rf["frac"]:.3f} of the
   2.5 PFLOP/s peak as the step runs it** ({rf["avg_launch_us"]:.0f} us per launch by HIP events on the second stream; the rocprofv3 summary of the
   profiled run says {avg:.0f} us -> {ru["avg_launch_gflop"] / avg / 2.5:.3f}, and that run printed {ru["frac"]:.3f}) and {al["alone"]["frac"]:.3f} for the same launches alone
@@ -116,6 +118,11 @@ launch reading the bf16 mirror.
   workgroup): 39.67 and 40.45 ms against 34.8 (one-item-per-workgroup launches alone: +2-8 % per kernel alone - no
   prefetch across tile boundaries - and 35.74 against 34.56 ms in the step). Round 1's grouped launch looked better alone
   only because 108 busy CUs clock higher than 256.
+* Attention dK/dV with the live 32-key blocks of a sequence handed to the first waves / workgroups in order (so that the work
+  is proportional to the unmasked keys and the remaining workgroups leave after their prologue): parity-green, no change
+  (197-201 against 193-198 us with the benchmark's masks; with only a quarter of the keys live dK/dV still takes 160 us
+  against 215, where the forward drops from 117 to 43 and dQ from 150 to 65) - most of that kernel's time does not scale
+  with the live keys.
 * Attention dK/dV with every LDS read issued a phase ahead of its use (fenced phases: rows | scores + cols | softmax | grads):
   the schedule came out as intended (8 reads, then 8 MFMAs back to back) at 256 registers and 4 spilled - 200 us against 195
   for the compiler's own interleaving. The kernel's waits are not LDS latency: at two waves per SIMD its VALU is busy 57 %

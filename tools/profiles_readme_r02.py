@@ -121,8 +121,9 @@ launch reading the bf16 mirror.
 * Attention dK/dV with the live 32-key blocks of a sequence handed to the first waves / workgroups in order (so that the work
   is proportional to the unmasked keys and the remaining workgroups leave after their prologue): parity-green, no change
   (197-201 against 193-198 us with the benchmark's masks; with only a quarter of the keys live dK/dV still takes 160 us
-  against 215, where the forward drops from 117 to 43 and dQ from 150 to 65) - most of that kernel's time does not scale
-  with the live keys.
+  against 215, where the forward drops from 117 to 43 and dQ from 150 to 65): when the same one of every four workgroups is
+  live, the dispatcher's round-robin lands them on a quarter of the CUs (157 us with one live workgroup per (sequence, head),
+  204 with four); irregular lengths do not alias like that.
 * Attention dK/dV with every LDS read issued a phase ahead of its use (fenced phases: rows | scores + cols | softmax | grads):
   the schedule came out as intended (8 reads, then 8 MFMAs back to back) at 256 registers and 4 spilled - 200 us against 195
   for the compiler's own interleaving. The kernel's waits are not LDS latency: at two waves per SIMD its VALU is busy 57 %

@@ -163,10 +163,10 @@ __device__ __forceinline__ void stage_store(const Stage2& s, char* tile, int tid
 // Every kernel below runs the same pipeline: tile t+1 is fetched into registers while tile t is computed from LDS
 // stage t&1, written to the other stage when the compute is done, ONE barrier per tile.
 //
-// Dropout: element (query row, key) is kept iff stonk_pair_keep(stonk_pair_round1(rowkey(flat (b,h,q)), colkey(key >> 1)),
-// key odd ? C2_ODD : C2_EVEN) - one first hash round per PAIR of keys (common.h). Both keys are linear, so the kernels with
-// the query on the lane add a compile-time constant to the tile's pair key per two elements and the kernel with the key
-// on the lane does the same with the row key per element. The 1/(1-p) factor never touches an
+// Dropout: element (query row, key) is kept iff stonk_pair_keep(stonk_pair_round1(rowkey(flat (b,h,q)), colkey(key >> 2)),
+// C2_QUAD[key & 3]) - one first hash round per QUAD of keys (common.h). Both keys are linear, so the kernels with the query
+// on the lane add a compile-time constant to the tile's quad key per four elements and the kernel with the key on the lane
+// does the same with the row key per element. The 1/(1-p) factor never touches an
 // element: it is folded into the output normalisation (forward, dV) or into delta and the final scale (dQ, dK).
 
 // Workgroup -> (128-row block, head, sequence). Workgroups are dispatched round-robin over the 8 XCDs in linear order, so
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
   const bf16* vbase = p.v + tok0 * p.ld + h * HD;
   const int ntiles = S / TK;
   const uint32_t rk = stonk_rowkey((uint32_t)((b * p.NH + h) * S + q0 + r), p.seed);
-  const uint32_t ck_lane = stonk_colkey((uint32_t)(2 * hh));   // key PAIRS: this lane's keys start at 4 hh = pair 2 hh
+  const uint32_t ck_lane = stonk_colkey((uint32_t)hh);   // key QUADS: this lane's keys start at 4 hh = quad hh
 
   Stage2 sk, sv;
   long mreg = 1;
@@ -338,21 +338,23 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
       }
     }
     // O^T += V^T . P^T
-    const uint32_t ckt = ck_lane + (uint32_t)(kt * TK / 2) * STONK_G_COL;
+    const uint32_t ckt = ck_lane + (uint32_t)(kt * TK / 4) * STONK_G_COL;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         float e[8];
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) {   // elements j, j + 1 are keys 2m, 2m + 1 of one pair
-          e[j] = s[sub][8 * ks + j];
-          e[j + 1] = s[sub][8 * ks + j + 1];
+        for (int j = 0; j < 8; j += 4) {   // elements j .. j + 3 are the keys 4m .. 4m + 3 of one quad
+          uint32_t y8 = 0;
           if (DROPOUT) {
-            const uint32_t cj = (uint32_t)((sub * 32 + 16 * ks + 8 * (j >> 2) + (j & 3)) >> 1) * STONK_G_COL;
-            const uint32_t y8 = stonk_pair_round1(rk, ckt + cj);
-            e[j] = stonk_pair_keep(y8, STONK_C2_EVEN, p.drop_thr32) ? e[j] : 0.f;
-            e[j + 1] = stonk_pair_keep(y8, STONK_C2_ODD, p.drop_thr32) ? e[j + 1] : 0.f;
+            const uint32_t cj = (uint32_t)((sub * 32 + 16 * ks + 8 * (j >> 2)) >> 2) * STONK_G_COL;
+            y8 = stonk_pair_round1(rk, ckt + cj);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            e[j + u] = s[sub][8 * ks + j + u];
+            if (DROPOUT) e[j + u] = stonk_pair_keep(y8, STONK_C2_QUAD[u], p.drop_thr32) ? e[j + u] : 0.f;
           }
         }
         const bf16x8 pf = pack8(e);
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const bf16* vbase = p.v + tok0 * p.ld + h * HD;
   const int ntiles = S / TK;
   const uint32_t rk = stonk_rowkey((uint32_t)stat, p.seed);
-  const uint32_t ck_lane = stonk_colkey((uint32_t)(2 * hh));   // key pairs, as in the forward
+  const uint32_t ck_lane = stonk_colkey((uint32_t)hh);   // key quads, as in the forward
 
   Stage2 sk, sv;
   long mreg = 1;
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     const int nx = rem ? __builtin_ctzll(rem) : -1;
     rem &= rem - 1;
     if (nx >= 0) load_tile(nx);
-    const uint32_t ckt = ck_lane + (uint32_t)(kt * TK / 2) * STONK_G_COL;
+    const uint32_t ckt = ck_lane + (uint32_t)(kt * TK / 4) * STONK_G_COL;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16 s, dp;
@@ -477,16 +479,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
         s = mfma32(row_frag(Ks, sub * 32, st, r, hh), qf[st], s);      // S^T[k][q] (+ key bias)
         dp = mfma32(row_frag(Vs, sub * 32, st, r, hh), dof[st], dp);   // dP^T[k][q] = sum_d V[k][d] dO[q][d]
       }
+      uint32_t y8q = 0;
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
         const f32x2 a = pk_fma((f32x2){s[i], s[i + 1]}, (f32x2){sc2, sc2}, (f32x2){nlse2, nlse2});
         const f32x2 pr = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
         f32x2 dpv = {dp[i], dp[i + 1]};
         if (DROPOUT) {
-          const uint32_t cj = (uint32_t)((sub * 32 + 8 * (i >> 2) + (i & 3)) >> 1) * STONK_G_COL;
-          const uint32_t y8 = stonk_pair_round1(rk, ckt + cj);
-          dpv[0] = stonk_pair_keep(y8, STONK_C2_EVEN, p.drop_thr32) ? dpv[0] : 0.f;
-          dpv[1] = stonk_pair_keep(y8, STONK_C2_ODD, p.drop_thr32) ? dpv[1] : 0.f;
+          if ((i & 2) == 0) y8q = stonk_pair_round1(rk, ckt + (uint32_t)((sub * 32 + 8 * (i >> 2)) >> 2) * STONK_G_COL);
+          dpv[0] = stonk_pair_keep(y8q, STONK_C2_QUAD[i & 2], p.drop_thr32) ? dpv[0] : 0.f;
+          dpv[1] = stonk_pair_keep(y8q, STONK_C2_QUAD[(i & 2) + 1], p.drop_thr32) ? dpv[1] : 0.f;
         }
         const f32x2 ds = pr * (dpv - (f32x2){dlt_s, dlt_s});  // dS^T (up to the folded 1/(1-p))
         s[i] = ds[0];
@@ -558,8 +560,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   const long statbase = (long)(b * p.NH + h) * S;
   const int ntiles = S / TK;
   const uint32_t rk_lane = stonk_rowkey((uint32_t)(statbase + 4 * hh), p.seed);
-  const uint32_t ck = stonk_colkey((uint32_t)((k0 + r) >> 1));                   // this lane's key: its pair ...
-  const uint32_t c2 = ((k0 + r) & 1) ? STONK_C2_ODD : STONK_C2_EVEN;              // ... and its half of it
+  const uint32_t ck = stonk_colkey((uint32_t)((k0 + r) >> 2));   // this lane's key: its quad ...
+  const uint32_t c2 = stonk_quad_c2((uint32_t)(k0 + r));         // ... and its place in it
   const float inv_ds = DROPOUT ? 1.f / p.drop_scale : 1.f;
 
   Stage2 sq, sd;

@@ -100,13 +100,17 @@ __device__ __forceinline__ bool stonk_keep_key(uint32_t rowkey, uint32_t colkey,
   const uint32_t y = __umul24(x, 0xB5297Bu) + x;
   return __umul24(y >> 8, 0x68E31Du) >= thr32;
 }
-// The same generator for a PAIR of neighbouring columns (2j, 2j+1) - the attention probabilities' dropout: the first
-// round is computed once per pair from the pair's key (colkey(j)), the last round twice with different multipliers; the
-// even column's decision is stonk_keep_key(rowkey, colkey(j)). A lane that walks the keys of one query (forward, dQ) pays
-// 5 VALU operations per score instead of 7; a lane that owns one key (dK/dV) keeps its multiplier in a register and pays
-// what it paid. Keep rate, row / column sums and the joint drop rates inside a pair, across pairs, along rows, columns
-// and 2x2 minors are those of independent draws (checked offline as above).
-constexpr uint32_t STONK_C2_EVEN = 0x68E31Du, STONK_C2_ODD = 0x9E3779u;
+// The same generator for a QUAD of neighbouring columns (4j .. 4j+3) - the attention probabilities' dropout: the first
+// round is computed once per quad from the quad's key (colkey(j)), the last round four times with different multipliers;
+// column 4j's decision is stonk_keep_key(rowkey, colkey(j)). A lane that walks the keys of one query (forward, dQ: four
+// consecutive keys per accumulator group) pays 4 VALU operations per score instead of 7; a lane that owns one key (dK/dV)
+// keeps its multiplier in a register and pays what it paid. Keep rate, row / column sums and the joint drop rates inside
+// a quad (pairs and triples), across quads, along rows, columns and 2x2 minors are those of independent draws (checked
+// offline as above, twelve seed / row-range combinations).
+constexpr uint32_t STONK_C2_QUAD[4] = {0x68E31Du, 0x9E3779u, 0xC2B2AFu, 0x27D4EBu};
+__device__ __forceinline__ uint32_t stonk_quad_c2(uint32_t col) {
+  return (col & 2) ? ((col & 1) ? 0x27D4EBu : 0xC2B2AFu) : ((col & 1) ? 0x9E3779u : 0x68E31Du);
+}
 __device__ __forceinline__ uint32_t stonk_pair_round1(uint32_t rowkey, uint32_t pairkey) {
   const uint32_t x = rowkey ^ pairkey;
   return (__umul24(x, 0xB5297Bu) + x) >> 8;

@@ -47,7 +47,8 @@ sec = f'''# profiles — round 2 (MI355X, gfx950, ROCm 7.2, one GPU)
   per pair of keys) took another 0.6 ms: forward 128 -> 112 us, dQ 161 -> 144, dK/dV 217 -> 197 per layer alone
   (`tools/prof_attention.sh`), 589 -> 522 us per layer in the step's profile; not visiting fully masked key tiles (the padding of
   the text half: 1.3 of 8 tiles per sequence in these batches) and dealing (sequence, head) pairs round-robin to the XCDs:
-  34.3 -> 33.9 ms.
+  34.3 -> 33.9 ms; the first hash round per quad of keys instead of per pair: another 0.15 ms. In the final profile below the
+  three attention kernels take 487 us per layer.
 * `roofline` (dominant kernel `gemm_tn_w4_kernel`, {rf["launches_per_step"]} launches per step, {rf["avg_launch_gflop"]:.1f} GFLOP each on average): **{rf["frac"]:.3f} of the
   2.5 PFLOP/s peak as the step runs it** ({rf["avg_launch_us"]:.0f} us per launch by HIP events on the second stream; the rocprofv3 summary of the
   profiled run says {avg:.0f} us -> {ru["avg_launch_gflop"] / avg / 2.5:.3f}, and that run printed {ru["frac"]:.3f}) and {al["alone"]["frac"]:.3f} for the same launches alone

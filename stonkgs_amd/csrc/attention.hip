@@ -163,7 +163,7 @@ __device__ __forceinline__ void stage_store(const Stage2& s, char* tile, int tid
 // Every kernel below runs the same pipeline: tile t+1 is fetched into registers while tile t is computed from LDS
 // stage t&1, written to the other stage when the compute is done, ONE barrier per tile.
 //
-// Dropout: element (query row, key) is kept iff stonk_pair_keep(stonk_pair_round1(rowkey(flat (b,h,q)), colkey(key >> 2)),
+// Dropout: element (query row, key) is kept iff stonk_quad_keep(stonk_quad_round1(rowkey(flat (b,h,q)), colkey(key >> 2)),
 // C2_QUAD[key & 3]) - one first hash round per QUAD of keys (common.h). Both keys are linear, so the kernels with the query
 // on the lane add a compile-time constant to the tile's quad key per four elements and the kernel with the key on the lane
 // does the same with the row key per element. The 1/(1-p) factor never touches an
@@ -349,12 +349,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
           uint32_t y8 = 0;
           if (DROPOUT) {
             const uint32_t cj = (uint32_t)((sub * 32 + 16 * ks + 8 * (j >> 2)) >> 2) * STONK_G_COL;
-            y8 = stonk_pair_round1(rk, ckt + cj);
+            y8 = stonk_quad_round1(rk, ckt + cj);
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             e[j + u] = s[sub][8 * ks + j + u];
-            if (DROPOUT) e[j + u] = stonk_pair_keep(y8, STONK_C2_QUAD[u], p.drop_thr32) ? e[j + u] : 0.f;
+            if (DROPOUT) e[j + u] = stonk_quad_keep(y8, STONK_C2_QUAD[u], p.drop_thr32) ? e[j + u] : 0.f;
           }
         }
         const bf16x8 pf = pack8(e);
@@ -486,9 +486,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
         const f32x2 pr = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
         f32x2 dpv = {dp[i], dp[i + 1]};
         if (DROPOUT) {
-          if ((i & 2) == 0) y8q = stonk_pair_round1(rk, ckt + (uint32_t)((sub * 32 + 8 * (i >> 2)) >> 2) * STONK_G_COL);
-          dpv[0] = stonk_pair_keep(y8q, STONK_C2_QUAD[i & 2], p.drop_thr32) ? dpv[0] : 0.f;
-          dpv[1] = stonk_pair_keep(y8q, STONK_C2_QUAD[(i & 2) + 1], p.drop_thr32) ? dpv[1] : 0.f;
+          if ((i & 2) == 0) y8q = stonk_quad_round1(rk, ckt + (uint32_t)((sub * 32 + 8 * (i >> 2)) >> 2) * STONK_G_COL);
+          dpv[0] = stonk_quad_keep(y8q, STONK_C2_QUAD[i & 2], p.drop_thr32) ? dpv[0] : 0.f;
+          dpv[1] = stonk_quad_keep(y8q, STONK_C2_QUAD[(i & 2) + 1], p.drop_thr32) ? dpv[1] : 0.f;
         }
         const f32x2 ds = pr * (dpv - (f32x2){dlt_s, dlt_s});  // dS^T (up to the folded 1/(1-p))
         s[i] = ds[0];
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
               const uint32_t rj = (uint32_t)(sub * 32 + 8 * g + j + u) * STONK_G_ROW;
-              pd[u] = stonk_pair_keep(stonk_pair_round1(rkt + rj, ck), c2, p.drop_thr32) ? pr[u] : 0.f;
+              pd[u] = stonk_quad_keep(stonk_quad_round1(rkt + rj, ck), c2, p.drop_thr32) ? pr[u] : 0.f;
             }
           }
           // dS = P (drop(dP) - delta) = dropped P . dP + P . (-delta): one select per score instead of two

@@ -111,11 +111,11 @@ constexpr uint32_t STONK_C2_QUAD[4] = {0x68E31Du, 0x9E3779u, 0xC2B2AFu, 0x27D4EB
 __device__ __forceinline__ uint32_t stonk_quad_c2(uint32_t col) {
   return (col & 2) ? ((col & 1) ? 0x27D4EBu : 0xC2B2AFu) : ((col & 1) ? 0x9E3779u : 0x68E31Du);
 }
-__device__ __forceinline__ uint32_t stonk_pair_round1(uint32_t rowkey, uint32_t pairkey) {
+__device__ __forceinline__ uint32_t stonk_quad_round1(uint32_t rowkey, uint32_t pairkey) {
   const uint32_t x = rowkey ^ pairkey;
   return (__umul24(x, 0xB5297Bu) + x) >> 8;
 }
-__device__ __forceinline__ bool stonk_pair_keep(uint32_t y8, uint32_t c2, uint32_t thr32) { return __umul24(y8, c2) >= thr32; }
+__device__ __forceinline__ bool stonk_quad_keep(uint32_t y8, uint32_t c2, uint32_t thr32) { return __umul24(y8, c2) >= thr32; }
 __device__ __forceinline__ bool stonk_keep(uint32_t row, uint32_t col, uint32_t seedmix, uint32_t thr32) {
   return stonk_keep_key(stonk_rowkey(row, seedmix), stonk_colkey(col), thr32);
 }

@@ -63,7 +63,8 @@ def _relerr(a, b):
     return ((a.float() - b.float()).norm() / b.float().norm()).item()
 
 
-@pytest.mark.parametrize("B,S,NH,masked", [(1, 128, 1, False), (2, 256, 2, True), (3, 512, 12, True), (2, 256, 3, False)])
+@pytest.mark.parametrize("B,S,NH,masked", [(1, 128, 1, False), (2, 256, 2, True), (3, 512, 12, True), (2, 256, 3, False),
+                                          (4, 384, 2, True), (8, 128, 3, True)])   # (pairs divisible by 8: the XCD-interleaved order)
 def test_attention_fwd_bwd(hip, B, S, NH, masked):
     qkv, dout, mask = _inputs(B, S, NH, 11 + S, masked)
     o_ref, lse_ref, g_ref = _ref(qkv, mask, B, S, NH, dout)

@@ -119,6 +119,10 @@ launch reading the bf16 mirror.
   workgroup): 39.67 and 40.45 ms against 34.8 (one-item-per-workgroup launches alone: +2-8 % per kernel alone - no
   prefetch across tile boundaries - and 35.74 against 34.56 ms in the step). Round 1's grouped launch looked better alone
   only because 108 busy CUs clock higher than 256.
+* GELU and GELU' of the FFN-up forward epilogue evaluated for two elements at once in packed fp32 (`v_pk_fma_f32`,
+  `v_pk_mul_f32`; only the rcp / exp pairs and the sign transfer stay scalar): 23 % fewer VALU instructions in the kernel
+  (5080 -> 3912), bit-compatible results - and the same 255-267 us per launch and 33.7-34.0 against 34.0-34.1 ms per step:
+  that epilogue is paced by its 402 MB of stores (output and saved GELU'), not by its arithmetic.
 * Attention dK/dV with the live 32-key blocks of a sequence handed to the first waves / workgroups in order (so that the work
   is proportional to the unmasked keys and the remaining workgroups leave after their prologue): parity-green, no change
   (197-201 against 193-198 us with the benchmark's masks; with only a quarter of the keys live dK/dV still takes 160 us

@@ -112,6 +112,26 @@ def test_attention_skips_masked_key_tiles_exactly(hip):
     assert float(dqkv[dead][:, H:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("S", [1024, 2048])
+def test_attention_long_sequences_with_and_without_tile_skipping(hip, S):
+    """Up to 1024 keys the live-tile bits are computed (16 tiles); beyond that every tile is walked: both against torch,
+    with a mask that leaves whole tiles dead."""
+    B, NH = 1, 2
+    qkv, dout, _ = _inputs(B, S, NH, 91, False)
+    mask = torch.ones(B, S, dtype=torch.long, device="cuda")
+    mask[0, 70:S // 2 + 5] = 0
+    mask[0, S - 200:S - 64] = 0
+    o_ref, lse_ref, g_ref = _ref(qkv, mask, B, S, NH, dout)
+    out, lse = _run_fwd(hip, qkv, mask, B, S, NH)
+    torch.testing.assert_close(out.float(), o_ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(lse, lse_ref, rtol=1e-4, atol=2e-3)
+    dqkv = _run_bwd(hip, qkv, mask, out, dout, lse, B, S, NH)
+    H = NH * 64
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        e = _relerr(dqkv[:, sl], g_ref[:, sl])
+        assert e < 2e-2, (name, e)
+
+
 def test_attention_spike_forces_online_rescale(hip):
     """One key per tile dominates a query: exercises the running-max rescale branch (guide rule 26)."""
     B, S, NH = 1, 256, 1

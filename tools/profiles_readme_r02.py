@@ -119,6 +119,10 @@ launch reading the bf16 mirror.
   workgroup): 39.67 and 40.45 ms against 34.8 (one-item-per-workgroup launches alone: +2-8 % per kernel alone - no
   prefetch across tile boundaries - and 35.74 against 34.56 ms in the step). Round 1's grouped launch looked better alone
   only because 108 busy CUs clock higher than 256.
+* Dead QUERY rows (padded positions that carry no label: 95 of a sequence's 512 on average; reachable by reordering the
+  text half so that they sit together) skipped in the attention kernels - emulated with a fixed range of 96 rows per
+  sequence in a timing-only build before writing the reordering: forward 90 -> 88 us, dQ 122 -> 115, dK/dV 199 -> 176 per
+  layer alone, 0.4 ms per step at best - not built.
 * GELU and GELU' of the FFN-up forward epilogue evaluated for two elements at once in packed fp32 (`v_pk_fma_f32`,
   `v_pk_mul_f32`; only the rcp / exp pairs and the sign transfer stay scalar): 23 % fewer VALU instructions in the kernel
   (5080 -> 3912), bit-compatible results - and the same 255-267 us per launch and 33.7-34.0 against 34.0-34.1 ms per step:

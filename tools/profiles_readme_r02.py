@@ -18,6 +18,7 @@ d = json.load(open(os.path.join(R, "r02_final_bench.json")))
 up = json.load(open(os.path.join(R, "r02_bench_under_rocprof.json")))
 c4 = json.load(open(os.path.join(R, "r02_c4_24L1024_bench.json")))
 al = json.load(open(os.path.join(R, "r02_bench_roofline_alone.json")))["roofline"]
+lng = json.load(open(os.path.join(R, "r02_bench_1200_steps.json")))
 traffic = list(csv.reader(open(os.path.join(R, "r02_pmc_traffic.csv"))))
 tn = next(r for r in traffic if r[0].startswith("gemm_tn_w4"))
 mf = list(csv.reader(open(os.path.join(R, "r02_pmc_mfma.csv"))))
@@ -32,6 +33,7 @@ sec = f'''# profiles — round 2 (MI355X, gfx950, ROCm 7.2, one GPU)
 |---|---|---|
 | `r02_final_bench.json` | the JSON line of the bench as the driver runs it (N = 1, 20 steps, 5 warm-up, CPU baseline on) | `python bench.py --steps 20 --warmup 5` |
 | `r02_kernel_stats.csv`, `r02_bench_under_rocprof.json` | rocprofv3 per-kernel summary of the bench ({steps} steps: 2 warm-up + 5 timed + 2 instrumented, all with the weight gradients on the second stream) and the line it printed | `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline` |
+| `r02_bench_1200_steps.json`, `r02_power_clock_samples.log` | the bench over 1200 steps with socket power and shader clock sampled every 3 s beside it | `python bench.py --steps 1200 --warmup 3 --no-cpu-baseline --no-roofline` in the background, `rocm-smi --showpower --showclocks` in a shell loop |
 | `r02_bench_roofline_alone.json` | the bench with the labelled extra `roofline.alone` (the dominant kernel's launches without the second stream) | `python bench.py --steps 10 --warmup 5 --no-cpu-baseline --roofline-alone` |
 | `r02_pmc_traffic.csv` | per-kernel bytes at the L2's memory side (two passes, condensed by `tools/summarize_pmc.py`) | `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline`, then `--pmc WRITE_SIZE` |
 | `r02_pmc_mfma.csv`, `r02_c4_24L1024_pmc_mfma.csv` | per-kernel SQ counters (matrix-pipe utilisation, share of wave time parked / issue-stalled / issuing VALU / LDS), condensed by `tools/summarize_pmc_sq.py`; config 2 and config 4 | `rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE -- python3 bench.py [--model 24L1024] --steps 2 --warmup 1 --no-cpu-baseline --no-roofline` |
@@ -64,6 +66,11 @@ sec = f'''# profiles — round 2 (MI355X, gfx950, ROCm 7.2, one GPU)
   {mfc4:.3f}.
 * fabric traffic (`r02_pmc_traffic.csv`): {float(traffic[-1][5]):.1f} GB per step (round 1: 118); `gemm_tn_w4_kernel` {float(tn[3]):.0f} MB read + {float(tn[4]):.0f} MB of
   float atomics per launch.
+* sustained: `r02_bench_1200_steps.json` - the same bench for 1200 steps (41 s): {lng["value"]:.0f} pairs/s, {lng["ms_per_step"]:.2f} ms per step
+  on what was one of the slower boxes, with `r02_power_clock_samples.log` taken beside it (every 3 s): 1.98 GHz at 1340-1350 W from
+  the first sample under load to the last (round 1's log, another box, round 1's step: 2.2 GHz at 1290-1320 W) - the socket
+  sits at its power limit. Length of the run does not matter: 20 / 1200 / 20 / 300 steps in turn on ONE box read 34.18 / 34.23 /
+  34.26 / 34.10 ms per step; the difference to the headline is the box.
 * CPU baseline (the oracle, fp32, same model shape, batch 8): {d["cpu_baseline"]["value"]:.2f} pairs/s on the box's {d["cpu_baseline"]["cores"]} host threads, {d["cpu_baseline"]["at_8_threads"]["value"]:.2f} at 8.
 * config 4 (24L / 1024h, batch 64, `r02_c4_24L1024_bench.json`, under rocprofv3): {c4["value"]:.0f} pairs/s, {c4["ms_per_step"]:.1f} ms per step,
   1217 GFLOP per pair -> `step_mfma_frac` {c4["step_mfma_frac"]:.3f}; `gemm_tn_w4_kernel` is {c4tn:.0f} % of its GPU time.

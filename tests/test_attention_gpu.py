@@ -216,6 +216,35 @@ def test_attention_backward_replays_the_forward_mask_exactly(hip):
         assert e < 2e-2, (name, e)   # (a kernel replaying a different mask is off by order 1)
 
 
+def test_attention_dropout_is_independent_inside_a_key_quad(hip):
+    """The first hash round is shared by the four keys of a quad (common.h): the four decisions of one (query, quad) must
+    still look independent. Recover the mask of 16 whole quads through one-hot V rows (as above) at p = 0.25 and compare
+    every pairwise joint drop rate inside a quad with p^2 (a multiplier used twice would give p), the marginals with p."""
+    B, S, NH, p = 4, 256, 2, 0.25
+    H = NH * 64
+    qkv, _, _ = _inputs(B, S, NH, 41, False)
+    quads = torch.arange(16, device="cuda") * 4 * 3 + 8          # quads at keys 8, 20, 32, ... (every key tile, both halves)
+    keys = (quads[:, None] + torch.arange(4, device="cuda")[None, :]).flatten()
+    assert keys.numel() == 64 and int(keys.max()) < S and bool((keys.view(16, 4)[:, 0] % 4 == 0).all())
+    mask = torch.zeros(B, S, dtype=torch.long, device="cuda")
+    mask[:, keys] = 1
+    v = qkv.view(B, S, 3, NH, 64)
+    v[:, keys, 2] = torch.eye(64, device="cuda", dtype=torch.bfloat16)[None, :, None, :].expand(B, 64, NH, 64)
+    drops = []
+    for seed in (3, 4, 5):
+        out, _ = _run_fwd(hip, qkv, mask, B, S, NH, p, seed)
+        drops.append((out.float().view(B, S, NH, 16, 4) == 0).float())    # [.., quad, key in quad]
+    d = torch.cat(drops)
+    marg = d.mean(dim=(0, 1, 2, 3))
+    assert float((marg - p).abs().max()) < 0.01, marg
+    for a in range(4):
+        for c in range(a + 1, 4):
+            joint = float((d[..., a] * d[..., c]).mean())
+            assert abs(joint / (p * p) - 1.0) < 0.05, (a, c, joint)
+    across = float((d[..., :-1, 3] * d[..., 1:, 0]).mean())                 # neighbouring quads
+    assert abs(across / (p * p) - 1.0) < 0.05, across
+
+
 def test_attention_bad_shape(hip):
     qkv = torch.zeros(100, 192, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(hip.StonkHipError):

@@ -150,25 +150,24 @@ def cpu_baseline(cfg, seconds_budget=28.0):
 
 
 def spawn_ranks(args) -> int:
-    """`python bench.py --gpus N` with N > 1 outside a launcher: start N ranks (one per GPU, RCCL) through
-    torch.distributed.run as a CHILD process and relay its exit code; rank 0 of the child job prints the JSON line on the
-    inherited stdout. This parent never touches a GPU (a process that has initialised HIP must not be replaced or forked)."""
-    import socket
-    import subprocess
+    """`python bench.py --gpus N` with N > 1 outside a launcher: start N ranks (one per GPU, RCCL) as CHILD processes this
+    parent owns (stonkgs_amd/launch.py: explicit RANK / WORLD_SIZE environment, one session per rank, a wall limit after
+    which every rank is stopped and the exit code is non-zero) and relay rank 0's JSON line. The parent does no GPU work
+    and is never replaced: it only counts devices and waits."""
+    from stonkgs_amd.launch import run_ranks
 
-    n_dev = torch.cuda.device_count()   # (does not initialise the HIP runtime)
-    if n_dev < args.gpus:
+    n_dev = torch.cuda.device_count()   # (a device count only; the ranks are fresh processes either way)
+    if n_dev < args.gpus and os.environ.get("STONK_DIST_BACKEND", "nccl") == "nccl":
         print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible", file=sys.stderr, flush=True)
         return 2
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    log(f"spawning {args.gpus} ranks: {' '.join(cmd)}")
-    return subprocess.run(cmd, env=env).returncode
+    # generous: model build + warm-up + timed steps + instrumented steps; a hung rank ends the job here, not never
+    limit = float(os.environ.get("STONK_BENCH_WALL_LIMIT", 600 + 3.0 * (args.steps + args.warmup)))
+    log(f"spawning {args.gpus} ranks (wall limit {limit:.0f} s)")
+    res = run_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], timeout=limit, relay=True)
+    if res.returncode != 0:
+        why = "wall limit reached, ranks stopped" if res.timed_out else f"rank exit codes {res.codes}"
+        print(f"bench.py: {args.gpus}-rank job failed ({why})\n{res.tail(1500)}", file=sys.stderr, flush=True)
+    return res.returncode
 
 
 def main():

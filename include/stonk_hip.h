@@ -10,7 +10,8 @@
  *  - plain pointers and sizes only; all pointers are DEVICE addresses unless stated; bf16 = 16-bit brain
  *    float stored as uint16_t; "ld*" are row strides in ELEMENTS;
  *  - every launcher is asynchronous on `stream` (a hipStream_t passed as void*), allocates nothing, keeps no
- *    global state, never throws; it returns 0 on success, <0 for a rejected argument (STONK_E*), >0 for a
+ *    global state (a launcher that needs scratch memory takes a caller workspace and has a `*_workspace_floats` query),
+ *    never throws; it returns 0 on success, <0 for a rejected argument (STONK_E*), >0 for a
  *    hipError_t raised by the launch;
  *  - dropout masks are regenerated from (seed, element index) by a counter-based hash, never stored.
  */
@@ -96,17 +97,22 @@ int stonk_text_embed_ln_fwd(const int64_t* input_ids, int64_t ld_ids, const floa
 int stonk_embed_grad(const void* dx, const int64_t* token_type_ids, float* dpos, float* dtype, int B, int S, int H,
                      int type_rows, void* stream);
 
-/* Fused attention, head_dim 64, S % 128 == 0: out = dropout(softmax(q k^T * scale + mask)) v.
+/* Fused attention, head_dim 64, S % 128 == 0, S <= 4096: out = dropout(softmax(q k^T * scale + mask)) v.
  * q/k/v: column slices of the [T, 3H] projection (row stride ld), head h at columns h*64..; attention_mask int64
- * [B,S] (0 = masked key) or NULL; lse fp32 [B,NH,S]. Replaces hf:modeling_bert.py:188-203 (eager :111-136). */
+ * [B,S] (0 = masked key) or NULL; lse fp32 [B,NH,S]. Replaces hf:modeling_bert.py:188-203 (eager :111-136).
+ * PACKED layout (seq_offsets != NULL, int32 [B+1], device): sequence b is rows seq_offsets[b] .. seq_offsets[b+1]-1 of
+ * q/k/v/out (any length <= S, no alignment), attention_mask is then REQUIRED and holds one word per packed ROW; lse (and
+ * delta_ws) keep the [B,NH,S] layout. What the trainable encoder runs on once the rows that nothing reads - padding that
+ * is neither a live key nor a labelled position - are dropped (stonk_unpad_plan); rows outside every sequence are never
+ * read or written. */
 int stonk_attention_fwd(const void* q, const void* k, const void* v, int64_t ld, const int64_t* attention_mask,
-                        void* out, int64_t ldo, float* lse, int B, int NH, int S, int D, float scale, float drop_p,
-                        uint32_t seed, void* stream);
+                        const int* seq_offsets, void* out, int64_t ldo, float* lse, int B, int NH, int S, int D,
+                        float scale, float drop_p, uint32_t seed, void* stream);
 /* Backward of the above (recomputes P from lse; no atomics). delta_ws: fp32 [B,NH,S] scratch. */
 int stonk_attention_bwd(const void* q, const void* k, const void* v, int64_t ld, const int64_t* attention_mask,
-                        const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta_ws,
-                        void* dq, void* dk, int64_t ldd, void* dv, int B, int NH, int S, int D, float scale,
-                        float drop_p, uint32_t seed, void* stream);
+                        const int* seq_offsets, const void* out, int64_t ldo, const void* dout, int64_t lddo,
+                        const float* lse, float* delta_ws, void* dq, void* dk, int64_t ldd, void* dv, int B, int NH,
+                        int S, int D, float scale, float drop_p, uint32_t seed, void* stream);
 
 /* out[c][r] = in[r][c] (bf16). Rows >= *rows_dev (nullable) read as zero; colsum (nullable, fp32) += column sums
  * of `in` (bias gradients). Feeds wgrad operands to stonk_gemm_nt_bf16. */
@@ -188,8 +194,12 @@ int stonk_ratio_f32(const float* num, const float* den, float* out, void* stream
 int stonk_gelu_bwd_bf16(const void* dg, const void* u, void* du, int64_t n, void* stream);
 
 /* Optimizer step pieces (hf:trainer.py:1780-1796 as driven by ref:src/stonkgs/models/stonkgs_pretraining.py:171-223):
- * *out_accum += sum(x^2); fused clip_grad_norm_(max_grad_norm) + AdamW + bf16 weight refresh + grad zeroing. */
-int stonk_sumsq_f32(const float* x, int64_t n, float* out_accum, void* stream);
+ * *out_accum += sum(x^2), summed in a fixed order (bitwise repeatable: data-parallel replicas rely on it) through a caller
+ * workspace of stonk_sumsq_workspace_floats() floats - zero it once after allocating it; the kernel leaves it ready for
+ * the next launch; concurrent launches (different streams) need different workspaces;
+ * fused clip_grad_norm_(max_grad_norm) + AdamW + bf16 weight refresh + grad zeroing. */
+int64_t stonk_sumsq_workspace_floats(void);
+int stonk_sumsq_f32(const float* x, int64_t n, float* out_accum, float* workspace, int64_t ws_floats, void* stream);
 int stonk_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, float bias_corr1, float bias_corr2, const float* gnorm_sq_dev,
                      float max_grad_norm, float grad_scale, void* stream);

@@ -9,7 +9,8 @@ reference's own ``forward`` / HF BERT / torch AdamW on CPU, and stores inputs + 
 Nothing here runs on the GPU box; the fixtures it writes are data only (ints / floats / config numbers).
 
     python oracle/make_golden.py          # rewrites tests/golden/*.npz, *.json
-    python oracle/make_golden.py shape    # only g3_shapetrue; `f3` = only the TSV / checkpoint cases; `splits` = only g7
+    python oracle/make_golden.py shape    # only g3_shapetrue; `f3` = only the TSV / checkpoint cases; `splits` = only g7;
+                                          # `curve` / `curve_small` = only the loss-curve cases g11 / g12
 """
 from __future__ import annotations
 
@@ -377,6 +378,65 @@ def shape_true_case(name, sm, pre, cfg: orc.OracleConfig, B, seed):
     print(name, "loss", float(out.loss), "grad_norm", float(total_norm))
 
 
+def curve_case(name, sm, pre, cfg: orc.OracleConfig, B, seed, steps, lr, n_batches):
+    """G11/G12: the REFERENCE's loss curve and the reference's own mixed-precision envelope. The reference model (its own
+    forward, HF BERT, torch AdamW, clip 1.0, linear schedule: ref:src/stonkgs/models/stonkgs_pretraining.py:171-223 ->
+    hf:trainer.py:1780-1796) is trained twice from the same weights over the same batches, dropout off: once in fp32 and
+    once with the forward under torch.autocast (bf16 - the mixed-precision path a CPU has; the reference trains with
+    fp16=True on its GPUs, :178). Stored: the batches, both loss curves. |bf16 - fp32| per step is the deviation the
+    reference's own reduced-precision training shows from its fp32 run; the HIP path is held to it."""
+    from transformers import get_linear_schedule_with_warmup
+
+    sd = orc.init_state_dict(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    tsv_rows = torch.randn(cfg.kg_vocab_size, cfg.hidden_size, generator=g, dtype=torch.float64) * 0.3
+    batches = [make_batch(cfg, B, seed + 10 + i, pre) for i in range(n_batches)]
+    curves = {}
+    for mode in ("fp32", "bf16_autocast"):
+        model = build_reference_model(sm, cfg, sd, tsv_rows)
+        train_params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.AdamW(train_params, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+        sched = get_linear_schedule_with_warmup(opt, 0, steps)
+        losses = []
+        for i in range(steps):
+            batch = batches[i % n_batches]
+            model.zero_grad()
+            if mode == "fp32":
+                loss = model(**batch)[0]
+            else:
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    loss = model(**batch)[0]
+            loss.float().backward()
+            torch.nn.utils.clip_grad_norm_(train_params, 1.0)
+            opt.step()
+            sched.step()
+            losses.append(float(loss))
+            if i % 10 == 0 or i == steps - 1:
+                print(name, mode, "step", i, "loss", losses[-1], flush=True)
+        curves[mode] = np.array(losses, dtype=np.float64)
+        del model, opt
+    arrays = {"loss_fp32": curves["fp32"], "loss_bf16_autocast": curves["bf16_autocast"]}
+    for i, b in enumerate(batches):
+        for k, v in b.items():
+            arrays[f"b{i}::{k}"] = v.numpy()
+    d = curves["bf16_autocast"] - curves["fp32"]
+    meta = {"config": {k: getattr(cfg, k) for k in ("vocab_size", "kg_vocab_size", "hidden_size", "num_hidden_layers",
+                                                    "num_attention_heads", "intermediate_size",
+                                                    "max_position_embeddings", "type_vocab_size", "layer_norm_eps")},
+            "B": B, "weight_seed": seed, "table_seed": seed + 1, "batch_seeds": [seed + 10 + i for i in range(n_batches)],
+            "table_std": 0.3, "steps": steps, "learning_rate": lr, "n_batches": n_batches,
+            "weights_checksum": float(sum(v.double().abs().sum() for v in sd.values())),
+            "table_checksum": float(tsv_rows.abs().sum()),
+            "reference_bf16_vs_fp32": {"max_abs": float(np.abs(d).max()), "rms": float(np.sqrt((d ** 2).mean())),
+                                       "mean": float(d.mean())},
+            "torch": torch.__version__}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(name, "fp32", curves["fp32"][0], "->", curves["fp32"][-1], "| reference bf16-autocast vs fp32: max",
+          np.abs(d).max(), "rms", np.sqrt((d ** 2).mean()), "mean", d.mean())
+
+
 def import_reference_prepare_df():
     """The reference's own TSV reader, ref:src/stonkgs/models/kg_baseline_model.py:270-280, from the real module (the
     stub installed for importing stonkgs_model is bypassed). Its module-level imports of the experiment-tracking and
@@ -554,6 +614,17 @@ def main():
     torch.set_num_threads(4)
     sm, pre = import_reference()
     only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only in ("curve", "curve_small"):   # round 3: the reference's loss curves, fp32 and bf16 autocast (minutes of CPU)
+        torch.set_num_threads(8)
+        if only == "curve":
+            curve_case("g11_curve_shapetrue", sm, pre, orc.OracleConfig(kg_vocab_size=4096), B=2, seed=700, steps=60,
+                       lr=1e-4, n_batches=6)
+        else:
+            curve_case("g12_curve_small", sm, pre,
+                       orc.OracleConfig(vocab_size=512, kg_vocab_size=300, hidden_size=128, num_hidden_layers=2,
+                                        num_attention_heads=2, intermediate_size=256, max_position_embeddings=256),
+                       B=4, seed=800, steps=200, lr=1e-3, n_batches=6)
+        return
     if only in ("shape", "f3"):   # (re)generate only the round-2 cases
         if only == "shape":
             torch.set_num_threads(8)

@@ -44,8 +44,8 @@ _SIGNATURES = {
     "stonk_text_embed_ln_fwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _f32, _i32, _f32,
                                 _u32, _vp, _vp],
     "stonk_embed_grad": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
-    "stonk_attention_fwd": [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u32, _vp],
-    "stonk_attention_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i32,
+    "stonk_attention_fwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u32, _vp],
+    "stonk_attention_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i32,
                             _i32, _i32, _i32, _f32, _f32, _u32, _vp],
     "stonk_transpose_bf16": [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp],
     "stonk_transpose_f32_to_bf16": [_vp, _vp, _i64, _i32, _i64, _vp],
@@ -67,7 +67,7 @@ _SIGNATURES = {
     "stonk_dropout_f32": [_vp, _vp, _i64, _f32, _u32, _vp],
     "stonk_ratio_f32": [_vp, _vp, _vp, _vp],
     "stonk_gelu_bwd_bf16": [_vp, _vp, _vp, _i64, _vp],
-    "stonk_sumsq_f32": [_vp, _i64, _vp, _vp],
+    "stonk_sumsq_f32": [_vp, _i64, _vp, _vp, _i64, _vp],
     "stonk_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _f32, _f32,
                          _vp],
     "stonk_scale_f32": [_vp, _i64, _f32, _vp],
@@ -109,12 +109,15 @@ def lib():
         handle.stonk_abi_version.restype = C.c_int
         handle.stonk_layernorm_bwd_workspace_floats.argtypes = [_i64, _i32]   # a size query, not a launcher: returns the size
         handle.stonk_layernorm_bwd_workspace_floats.restype = C.c_int64
+        handle.stonk_sumsq_workspace_floats.argtypes = []
+        handle.stonk_sumsq_workspace_floats.restype = C.c_int64
         _lib = handle
     return _lib
 
 
 def exported_symbols():
-    return sorted(list(_SIGNATURES) + ["stonk_abi_version", "stonk_layernorm_bwd_workspace_floats"])
+    return sorted(list(_SIGNATURES) + ["stonk_abi_version", "stonk_layernorm_bwd_workspace_floats",
+                                     "stonk_sumsq_workspace_floats"])
 
 
 def check(status: int, name: str) -> None:

@@ -36,7 +36,8 @@ struct AttnArgs {
   const bf16* k;
   const bf16* v;
   long ld;            // row stride (elements) of q/k/v
-  const long* mask;   // [B,S] or null
+  const long* mask;   // [B,S] or null; with `cu`: one word per ROW of the packed layout (required)
+  const int* cu;      // null, or [B+1] row offsets: sequence b = rows cu[b] .. cu[b+1]-1 of q/k/v/out/dout/dq/dk/dv (<= S rows)
   bf16* out;          // fwd: context [T, ldo]; bwd: the forward's context (read)
   long ldo;
   float* lse;         // [B, NH, S] natural-log LSE of the scaled+masked scores
@@ -145,11 +146,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int c0, in
 struct Stage2 {
   bf16x8 c[2];
 };
-__device__ __forceinline__ void stage_load(Stage2& s, const bf16* base, long ld, int tid) {
+// rows row0 .. row0+63 of the sequence that starts at `base`; rows past the sequence's last one (n - 1) re-read that one:
+// finite values the callers mask out (a packed sequence's length need not be a multiple of the tile)
+__device__ __forceinline__ void stage_load(Stage2& s, const bf16* base, long ld, int row0, int n, int tid) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int id = tid + 256 * i;
-    s.c[i] = *(const bf16x8*)(base + (long)(id >> 3) * ld + (id & 7) * 8);
+    int row = row0 + (id >> 3);
+    row = row < n ? row : n - 1;
+    s.c[i] = *(const bf16x8*)(base + (long)row * ld + (id & 7) * 8);
   }
 }
 __device__ __forceinline__ void stage_store(const Stage2& s, char* tile, int tid) {
@@ -198,6 +203,18 @@ __device__ __forceinline__ AttnBlock attn_block() {
   return o;
 }
 
+// Rows of the block's sequence: [tok0, tok0 + n). Padded layout: n = S. Packed layout (p.cu): the sequence's own extent -
+// a 128-row block that starts past it has nothing to do and leaves (the grid is sized for S rows per sequence).
+#define SEQ_EXTENT()                                                     \
+  long tok0 = (long)b * S;                                               \
+  int n = S;                                                             \
+  if (p.cu) {                                                            \
+    tok0 = p.cu[b];                                                      \
+    n = p.cu[b + 1] - p.cu[b];                                           \
+    n = n < S ? n : S;                                                   \
+  }                                                                      \
+  if (blk.xb * 128 >= n) return
+
 // Key tiles (64 keys) of a sequence that hold at least one unmasked key, one bit per tile: a fully masked tile adds
 // exactly nothing to any query (its scores are -2^100 in raw units, their exp2 is 0), so the kernels with the keys in the
 // tile loop walk the set bits only - in the STonKGs layout the padding of the text half, 112 of 512 positions on average
@@ -214,12 +231,12 @@ __device__ __forceinline__ void live_issue(LiveTiles& t, const long* mask, long 
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int key = c * 256 + tid;   // the 64 lanes of a wave look at one tile
-    t.mv[c] = key < S ? mask[tok0 + key] : 0;
+    t.mv[c] = key < S ? mask[tok0 + key] : 0;   // (S: the rows of THIS sequence)
   }
 }
 template <bool HAS_MASK>
 __device__ __forceinline__ uint64_t live_finish(const LiveTiles& t, int S, int tid) {
-  const int nt = S / TK;
+  const int nt = (S + TK - 1) / TK;
   const uint64_t all = nt >= 64 ? ~0ull : ((1ull << nt) - 1);
   if (!HAS_MASK || S > 1024) return all;
   __shared__ int tile_live[16];
@@ -245,14 +262,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
   const int b = blk.b, h = blk.h;
   const int S = p.S;
   const int q0 = blk.xb * 128 + wave * 32;
-  const long tok0 = (long)b * S;
+  SEQ_EXTENT();
   const float sc2 = p.scale * LOG2E;
   LiveTiles lt;
-  live_issue<HAS_MASK>(lt, p.mask, tok0, S, tid);
+  live_issue<HAS_MASK>(lt, p.mask, tok0, n, tid);
 
+  const int qr = q0 + r < n ? q0 + r : n - 1;   // rows past the sequence re-read its last row; nothing is stored for them
   bf16x8 qf[4];
   {
-    const bf16* qrow = p.q + (tok0 + q0 + r) * p.ld + h * HD;
+    const bf16* qrow = p.q + (tok0 + qr) * p.ld + h * HD;
 #pragma unroll
     for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8*)(qrow + 16 * st + 8 * hh);
   }
@@ -263,16 +281,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
 
   const bf16* kbase = p.k + tok0 * p.ld + h * HD;
   const bf16* vbase = p.v + tok0 * p.ld + h * HD;
-  const int ntiles = S / TK;
+  const int ntiles = (n + TK - 1) / TK;
   const uint32_t rk = stonk_rowkey((uint32_t)((b * p.NH + h) * S + q0 + r), p.seed);
   const uint32_t ck_lane = stonk_colkey((uint32_t)hh);   // key QUADS: this lane's keys start at 4 hh = quad hh
 
   Stage2 sk, sv;
   long mreg = 1;
   auto load_tile = [&](int kt) {
-    stage_load(sk, kbase + (long)kt * TK * p.ld, p.ld, tid);
-    stage_load(sv, vbase + (long)kt * TK * p.ld, p.ld, tid);
-    if (HAS_MASK && tid < TK) mreg = p.mask[tok0 + kt * TK + tid];
+    stage_load(sk, kbase, p.ld, kt * TK, n, tid);
+    stage_load(sv, vbase, p.ld, kt * TK, n, tid);
+    if (HAS_MASK && tid < TK) mreg = kt * TK + tid < n ? p.mask[tok0 + kt * TK + tid] : 0;   // keys past the end: masked
   };
   auto store_tile = [&](int buf) {
     char* base = lds + buf * STAGEB;
@@ -281,7 +299,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
     if (HAS_MASK && tid < TK) ((float*)(base + 2 * TILEB))[tid] = mreg != 0 ? 0.f : NEG_MASK;
   };
   load_tile(0);   // (before the live bits are known: tile 0 almost always is - [CLS])
-  uint64_t rem = live_finish<HAS_MASK>(lt, S, tid);
+  uint64_t rem = live_finish<HAS_MASK>(lt, n, tid);
   if (rem == 0) rem = ntiles >= 64 ? ~0ull : ((1ull << ntiles) - 1);
   int kt = __builtin_ctzll(rem);
   rem &= rem - 1;
@@ -367,6 +385,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
     kt = nx;
   }
   const float inv = (DROPOUT ? p.drop_scale : 1.f) / l;
+  if (q0 + r >= n) return;
   bf16* orow = p.out + (tok0 + q0 + r) * p.ldo + h * HD;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -390,16 +409,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const int b = blk.b, h = blk.h;
   const int S = p.S;
   const int q0 = blk.xb * 128 + wave * 32;
-  const long tok0 = (long)b * S;
+  SEQ_EXTENT();
   LiveTiles lt;
-  live_issue<HAS_MASK>(lt, p.mask, tok0, S, tid);
+  live_issue<HAS_MASK>(lt, p.mask, tok0, n, tid);
 
+  const bool qlive = q0 + r < n;
+  const int qr = qlive ? q0 + r : n - 1;   // rows past the sequence re-read its last row; nothing is stored for them
   bf16x8 qf[4], dof[4];
   float dlt = 0.f;
   {
-    const bf16* qrow = p.q + (tok0 + q0 + r) * p.ld + h * HD;
-    const bf16* drow = p.dout + (tok0 + q0 + r) * p.lddo + h * HD;
-    const bf16* orow = p.out + (tok0 + q0 + r) * p.ldo + h * HD;
+    const bf16* qrow = p.q + (tok0 + qr) * p.ld + h * HD;
+    const bf16* drow = p.dout + (tok0 + qr) * p.lddo + h * HD;
+    const bf16* orow = p.out + (tok0 + qr) * p.ldo + h * HD;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       qf[st] = *(const bf16x8*)(qrow + 16 * st + 8 * hh);
@@ -411,8 +432,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   }
   dlt += __shfl_xor(dlt, 32, 64);
   const long stat = (long)(b * p.NH + h) * S + q0 + r;
-  if (hh == 0) p.delta[stat] = dlt;
-  const float lse_q = p.lse[stat];
+  if (hh == 0 && qlive) p.delta[stat] = dlt;
+  const float lse_q = p.lse[stat - (q0 + r) + qr];
   // dS = P * (drop(dP) - delta) with drop(dP) = keep ? dP / (1-p) : 0  ==  (1/(1-p)) * P * ((keep ? dP : 0) - (1-p) delta)
   const float dlt_s = DROPOUT ? dlt / p.drop_scale : dlt;
   f32x16 dq[2];
@@ -421,16 +442,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
 
   const bf16* kbase = p.k + tok0 * p.ld + h * HD;
   const bf16* vbase = p.v + tok0 * p.ld + h * HD;
-  const int ntiles = S / TK;
+  const int ntiles = (n + TK - 1) / TK;
   const uint32_t rk = stonk_rowkey((uint32_t)stat, p.seed);
   const uint32_t ck_lane = stonk_colkey((uint32_t)hh);   // key quads, as in the forward
 
   Stage2 sk, sv;
   long mreg = 1;
   auto load_tile = [&](int kt) {
-    stage_load(sk, kbase + (long)kt * TK * p.ld, p.ld, tid);
-    stage_load(sv, vbase + (long)kt * TK * p.ld, p.ld, tid);
-    if (HAS_MASK && tid < TK) mreg = p.mask[tok0 + kt * TK + tid];
+    stage_load(sk, kbase, p.ld, kt * TK, n, tid);
+    stage_load(sv, vbase, p.ld, kt * TK, n, tid);
+    if (HAS_MASK && tid < TK) mreg = kt * TK + tid < n ? p.mask[tok0 + kt * TK + tid] : 0;   // keys past the end: masked
   };
   auto store_tile = [&](int buf) {
     char* base = lds + buf * STAGEB;
@@ -439,14 +460,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     if (HAS_MASK && tid < TK) ((float*)(base + 2 * TILEB))[tid] = mreg != 0 ? 0.f : NEG_MASK;
   };
   load_tile(0);   // (before the live bits are known)
-  uint64_t rem = live_finish<HAS_MASK>(lt, S, tid);
+  uint64_t rem = live_finish<HAS_MASK>(lt, n, tid);
   // No unmasked key in the whole sequence: the reference's finfo.min absorbs every score and it attends uniformly, P = 1/S.
   // The forward gets there by the same absorption; its log-sum-exp (-2^100-sized) cannot carry log S, so the backward
   // kernels rebuild P from a zero score scale and lse = log S. (Never the case in a STonKGs batch - [CLS] is always live.)
   const bool uniform = rem == 0;
   if (uniform) rem = ntiles >= 64 ? ~0ull : ((1ull << ntiles) - 1);
   const float sc2 = uniform ? 0.f : p.scale * LOG2E;
-  const float nlse2 = uniform ? -__builtin_amdgcn_logf((float)S) : -lse_q * LOG2E;   // (v_log_f32 is log2)
+  const float nlse2 = uniform ? -__builtin_amdgcn_logf((float)n) : -lse_q * LOG2E;   // (v_log_f32 is log2)
   int kt = __builtin_ctzll(rem);
   rem &= rem - 1;
   if (kt != 0) load_tile(kt);
@@ -510,6 +531,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
     kt = nx;
   }
   const float fs = DROPOUT ? p.scale * p.drop_scale : p.scale;
+  if (!qlive) return;
   bf16* orow = p.dq + (tok0 + q0 + r) * p.ldd + h * HD;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -531,14 +553,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   const int b = blk.b, h = blk.h;
   const int S = p.S;
   const int k0 = blk.xb * 128 + wave * 32;
-  const long tok0 = (long)b * S;
+  SEQ_EXTENT();
   LiveTiles lt;
-  live_issue<HAS_MASK>(lt, p.mask, tok0, S, tid);
+  live_issue<HAS_MASK>(lt, p.mask, tok0, n, tid);
 
+  const bool klive = k0 + r < n;
+  const int kr = klive ? k0 + r : n - 1;   // keys past the sequence re-read its last row, count as masked, store nothing
   bf16x8 kf[4], vf[4];
   {
-    const bf16* krow = p.k + (tok0 + k0 + r) * p.ld + h * HD;
-    const bf16* vrow = p.v + (tok0 + k0 + r) * p.ld + h * HD;
+    const bf16* krow = p.k + (tok0 + kr) * p.ld + h * HD;
+    const bf16* vrow = p.v + (tok0 + kr) * p.ld + h * HD;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       kf[st] = *(const bf16x8*)(krow + 16 * st + 8 * hh);
@@ -546,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
     }
   }
   float mb = 0.f;
-  if (HAS_MASK) mb = p.mask[tok0 + k0 + r] != 0 ? 0.f : NEG_MASK;
+  if (HAS_MASK) mb = (klive && p.mask[tok0 + kr] != 0) ? 0.f : NEG_MASK;
   // Masked keys get exactly zero gradient (P = 0 for every query), unless NO key of the sequence is unmasked (the reference
   // then attends uniformly): a wave whose 32 keys are all masked skips its arithmetic - its accumulators stay zero and it
   // only helps to stage the tiles - and a workgroup whose 128 keys are all masked writes its zeros and leaves.
@@ -558,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   const bf16* qbase = p.q + tok0 * p.ld + h * HD;
   const bf16* dbase = p.dout + tok0 * p.lddo + h * HD;
   const long statbase = (long)(b * p.NH + h) * S;
-  const int ntiles = S / TK;
+  const int ntiles = (n + TK - 1) / TK;
   const uint32_t rk_lane = stonk_rowkey((uint32_t)(statbase + 4 * hh), p.seed);
   const uint32_t ck = stonk_colkey((uint32_t)((k0 + r) >> 2));   // this lane's key: its quad ...
   const uint32_t c2 = stonk_quad_c2((uint32_t)(k0 + r));         // ... and its place in it
@@ -569,22 +593,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   // touched when the tile is stored (arithmetic at the load would wait for it, and for the tile loads issued before it,
   // at the top of every iteration).
   float sreg = 0.f;
+  bool slive = true;   // the statistics word in flight belongs to a query of this sequence
   const float* sptr = tid < TK ? p.lse + statbase + tid : p.delta + statbase + tid - TK;
   const float sfac = tid < TK ? -LOG2E : -inv_ds;
-  const float nlog2s = -__builtin_amdgcn_logf((float)S);
+  const float nlog2s = -__builtin_amdgcn_logf((float)n);
   auto load_tile = [&](int qt) {
-    stage_load(sq, qbase + (long)qt * TK * p.ld, p.ld, tid);
-    stage_load(sd, dbase + (long)qt * TK * p.lddo, p.lddo, tid);
-    if (tid < 2 * TK) sreg = sptr[qt * TK];
+    stage_load(sq, qbase, p.ld, qt * TK, n, tid);
+    stage_load(sd, dbase, p.lddo, qt * TK, n, tid);
+    if (tid < 2 * TK) {
+      slive = qt * TK + (tid & (TK - 1)) < n;
+      sreg = sptr[qt * TK];      // (inside the [B,NH,S] statistics arrays also past the sequence: S % 128 == 0)
+    }
   };
+  // a query row past the sequence's end (its Q / dO are re-reads of the last row) gets -lse = NEG_MASK, which makes its
+  // P exactly zero for every key, and delta = 0: it adds nothing to dK and dV
   auto store_tile = [&](int buf) {
     char* base = lds + buf * STAGEB;
     stage_store(sq, base, tid);
     stage_store(sd, base + TILEB, tid);
-    if (tid < 2 * TK) ((float*)(base + 2 * TILEB))[tid] = (uniform && tid < TK) ? nlog2s : sreg * sfac;
+    if (tid < 2 * TK)
+      ((float*)(base + 2 * TILEB))[tid] = !slive ? (tid < TK ? NEG_MASK : 0.f) : (uniform && tid < TK) ? nlog2s : sreg * sfac;
   };
   load_tile(0);   // (before the live bits are known; a workgroup that then leaves has asked for one tile in vain)
-  const uint64_t seq = live_finish<HAS_MASK>(lt, S, tid);
+  const uint64_t seq = live_finish<HAS_MASK>(lt, n, tid);
   uniform = seq == 0;
   const float sc2 = uniform ? 0.f : p.scale * LOG2E;
   bool wave_live = true, wg_live = true;
@@ -662,6 +693,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   }
   const float fk = DROPOUT ? p.scale * p.drop_scale : p.scale;
   const float fv = DROPOUT ? p.drop_scale : 1.f;
+  if (!klive) return;
   bf16* krow = p.dk + (tok0 + k0 + r) * p.ldd + h * HD;
   bf16* vrow = p.dv + (tok0 + k0 + r) * p.ldd + h * HD;
 #pragma unroll
@@ -680,7 +712,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
 int check_common(const void* q, const void* k, const void* v, int64_t ld, int B, int NH, int S, int D) {
   STONK_CHECK_ARG(q && k && v, STONK_EINVAL);
   STONK_CHECK_ARG(D == HD, STONK_ESHAPE);
-  STONK_CHECK_ARG(B >= 0 && NH > 0 && S > 0 && S % 128 == 0, STONK_ESHAPE);
+  // (the kernels keep one bit per 64-key tile of a sequence in a 64-bit word: 4096 keys)
+  STONK_CHECK_ARG(B >= 0 && NH > 0 && S > 0 && S % 128 == 0 && S <= 4096, STONK_ESHAPE);
   STONK_CHECK_ARG(ld % 8 == 0, STONK_EALIGN);
   STONK_CHECK_ARG((uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0, STONK_EALIGN);
   STONK_CHECK_ARG((long)B * NH * S < (1L << 32), STONK_ESHAPE);  // 32-bit dropout row counter
@@ -690,16 +723,18 @@ int check_common(const void* q, const void* k, const void* v, int64_t ld, int B,
 }  // namespace
 
 extern "C" int stonk_attention_fwd(const void* q, const void* k, const void* v, int64_t ld,
-                                   const int64_t* attention_mask, void* out, int64_t ldo, float* lse, int B, int NH,
-                                   int S, int D, float scale, float drop_p, uint32_t seed, void* stream) {
+                                   const int64_t* attention_mask, const int* seq_offsets, void* out, int64_t ldo,
+                                   float* lse, int B, int NH, int S, int D, float scale, float drop_p, uint32_t seed,
+                                   void* stream) {
   int rc = check_common(q, k, v, ld, B, NH, S, D);
   if (rc) return rc;
   STONK_CHECK_ARG(out && ldo % 4 == 0, STONK_EINVAL);
+  STONK_CHECK_ARG(!seq_offsets || attention_mask, STONK_EINVAL);   // packed rows carry their key mask
   STONK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, STONK_EINVAL);
   if (B == 0) return STONK_OK;
   AttnArgs a = {};
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
-  a.mask = (const long*)attention_mask; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse;
+  a.mask = (const long*)attention_mask; a.cu = seq_offsets; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse;
   a.B = B; a.NH = NH; a.S = S; a.scale = scale;
   a.drop_thr32 = stonk_drop_thr32(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = stonk_seed_mix(seed);
   const dim3 grid(S / 128, NH, B), block(256);
@@ -713,19 +748,20 @@ extern "C" int stonk_attention_fwd(const void* q, const void* k, const void* v, 
 }
 
 extern "C" int stonk_attention_bwd(const void* q, const void* k, const void* v, int64_t ld,
-                                   const int64_t* attention_mask, const void* out, int64_t ldo, const void* dout,
+                                   const int64_t* attention_mask, const int* seq_offsets, const void* out, int64_t ldo, const void* dout,
                                    int64_t lddo, const float* lse, float* delta_ws, void* dq, void* dk, int64_t ldd,
                                    void* dv, int B, int NH, int S, int D, float scale, float drop_p, uint32_t seed,
                                    void* stream) {
   int rc = check_common(q, k, v, ld, B, NH, S, D);
   if (rc) return rc;
   STONK_CHECK_ARG(out && dout && lse && delta_ws && dq && dk && dv, STONK_EINVAL);
+  STONK_CHECK_ARG(!seq_offsets || attention_mask, STONK_EINVAL);
   STONK_CHECK_ARG(ldo % 8 == 0 && lddo % 8 == 0 && ldd % 4 == 0, STONK_EALIGN);
   STONK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, STONK_EINVAL);
   if (B == 0) return STONK_OK;
   AttnArgs a = {};
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
-  a.mask = (const long*)attention_mask; a.lse = (float*)lse; a.out = (bf16*)out; a.ldo = ldo;
+  a.mask = (const long*)attention_mask; a.cu = seq_offsets; a.lse = (float*)lse; a.out = (bf16*)out; a.ldo = ldo;
   a.dout = (const bf16*)dout; a.lddo = lddo; a.delta = delta_ws;
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ldd = ldd;
   a.B = B; a.NH = NH; a.S = S; a.scale = scale;

@@ -411,4 +411,4 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   }
 }
 
-extern "C" int stonk_abi_version(void) { return 2; }
+extern "C" int stonk_abi_version(void) { return 3; }

@@ -13,13 +13,13 @@ namespace {
 // Sum of squares in a FIXED order: every block leaves its partial sum in a slot, the last block to finish (ticket) adds
 // the slots up in index order. With one atomicAdd per block the result depended on arrival order in its last bits - and
 // with it the clip coefficient and every parameter update, so data-parallel ranks holding identical summed gradients
-// drifted apart by an ulp per step (found with tools/dp_check.py). One optimizer stream per process is assumed
-// (the slots are library globals).
+// drifted apart by an ulp per step (found with tools/dp_check.py). Slots and ticket live in a CALLER workspace
+// (stonk_sumsq_workspace_floats(): SUMSQ_MAX_BLOCKS slots + the ticket word, zeroed once by the caller; the kernel
+// leaves the ticket at zero), so launches on different streams with different workspaces do not meet.
 constexpr int SUMSQ_MAX_BLOCKS = 1024;
-__device__ float g_sumsq_part[SUMSQ_MAX_BLOCKS];
-__device__ unsigned g_sumsq_ticket = 0;
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out,
+                                                    float* __restrict__ g_sumsq_part, unsigned* __restrict__ ticket) {
   float acc = 0.f;
   const long n4 = n >> 2;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     __hip_atomic_store(&g_sumsq_part[blockIdx.x], part[0] + part[1] + part[2] + part[3], __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();   // the slot is visible device-wide before the ticket is taken
-    const unsigned t = __hip_atomic_fetch_add(&g_sumsq_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     last = (t == gridDim.x - 1);
   }
   __syncthreads();
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   __syncthreads();
   if (threadIdx.x == 0) {
     atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
-    __hip_atomic_store(&g_sumsq_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
   }
 }
 
@@ -250,12 +250,17 @@ inline int ew_grid(long n) {
 
 }  // namespace
 
-extern "C" int stonk_sumsq_f32(const float* x, int64_t n, float* out_accum, void* stream) {
-  STONK_CHECK_ARG(x && out_accum && n >= 0, STONK_EINVAL);
-  STONK_CHECK_ARG((uintptr_t)x % 16 == 0, STONK_EALIGN);
+extern "C" int64_t stonk_sumsq_workspace_floats(void) { return SUMSQ_MAX_BLOCKS + 1; }
+
+extern "C" int stonk_sumsq_f32(const float* x, int64_t n, float* out_accum, float* workspace, int64_t ws_floats,
+                               void* stream) {
+  STONK_CHECK_ARG(x && out_accum && workspace && n >= 0, STONK_EINVAL);
+  STONK_CHECK_ARG(ws_floats >= SUMSQ_MAX_BLOCKS + 1, STONK_EINVAL);
+  STONK_CHECK_ARG((uintptr_t)x % 16 == 0 && (uintptr_t)workspace % 4 == 0, STONK_EALIGN);
   if (n == 0) return STONK_OK;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid(n) < 1024 ? ew_grid(n) : 1024), dim3(256), 0, (hipStream_t)stream, x,
-                     (long)n, out_accum);
+  const int grid = ew_grid(n) < SUMSQ_MAX_BLOCKS ? ew_grid(n) : SUMSQ_MAX_BLOCKS;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (long)n, out_accum, workspace,
+                     (unsigned*)(workspace + SUMSQ_MAX_BLOCKS));
   return stonk_launch_status();
 }
 

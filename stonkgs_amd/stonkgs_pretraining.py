@@ -71,6 +71,9 @@ class FusedAdamW:
         self.m = torch.zeros_like(store.data)
         self.v = torch.zeros_like(store.data)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=store.data.device)
+        # partial sums + ticket of the fixed-order grad-norm reduction (zeroed once; the kernel leaves it ready)
+        self.norm_ws = torch.zeros(int(hip.lib().stonk_sumsq_workspace_floats()), dtype=torch.float32,
+                                   device=store.data.device)
         self.step_count = 0
 
     def step(self, lr: float, grad_scale: float = 1.0) -> None:
@@ -79,7 +82,8 @@ class FusedAdamW:
         self.step_count += 1
         b1, b2 = self.betas
         self.gnorm_sq.zero_()
-        hip.call("stonk_sumsq_f32", s.grad.data_ptr(), s.numel, self.gnorm_sq.data_ptr(), st)
+        hip.call("stonk_sumsq_f32", s.grad.data_ptr(), s.numel, self.gnorm_sq.data_ptr(), self.norm_ws.data_ptr(),
+                 self.norm_ws.numel(), st)
         if self.weight_decay:   # decoupled decay, p *= 1 - lr * wd, on the decayed tensors only and before the Adam update
             for name in self.decayed:   # (torch.optim.AdamW's order); the fused kernel below then runs with wd = 0
                 v = s.view(name, padded=True)

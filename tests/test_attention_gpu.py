@@ -25,22 +25,22 @@ def _ref(qkv, mask, B, S, NH, dout=None):
     return o.detach(), lse.detach(), grads
 
 
-def _run_fwd(hip, qkv, mask, B, S, NH, drop_p=0.0, seed=0):
+def _run_fwd(hip, qkv, mask, B, S, NH, drop_p=0.0, seed=0, cu=None):
     H = NH * 64
-    out = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16)
-    lse = torch.empty(B, NH, S, device="cuda")
+    out = torch.full((qkv.shape[0], H), 7.0, device="cuda", dtype=torch.bfloat16)
+    lse = torch.full((B, NH, S), float("nan"), device="cuda")
     hip.call("stonk_attention_fwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask),
-             hip.ptr(out), H, hip.ptr(lse), B, NH, S, 64, 0.125, drop_p, seed, hip.stream_ptr())
+             hip.ptr(cu), hip.ptr(out), H, hip.ptr(lse), B, NH, S, 64, 0.125, drop_p, seed, hip.stream_ptr())
     return out, lse
 
 
-def _run_bwd(hip, qkv, mask, out, dout, lse, B, S, NH, drop_p=0.0, seed=0):
+def _run_bwd(hip, qkv, mask, out, dout, lse, B, S, NH, drop_p=0.0, seed=0, cu=None):
     H = NH * 64
     dqkv = torch.zeros_like(qkv)
-    delta = torch.empty(B, NH, S, device="cuda")
+    delta = torch.full((B, NH, S), float("nan"), device="cuda")
     hip.call("stonk_attention_bwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask),
-             hip.ptr(out), H, hip.ptr(dout), H, hip.ptr(lse), hip.ptr(delta), hip.ptr(dqkv), hip.ptr(dqkv) + 2 * H,
-             3 * H, hip.ptr(dqkv) + 4 * H, B, NH, S, 64, 0.125, drop_p, seed, hip.stream_ptr())
+             hip.ptr(cu), hip.ptr(out), H, hip.ptr(dout), H, hip.ptr(lse), hip.ptr(delta), hip.ptr(dqkv),
+             hip.ptr(dqkv) + 2 * H, 3 * H, hip.ptr(dqkv) + 4 * H, B, NH, S, 64, 0.125, drop_p, seed, hip.stream_ptr())
     return dqkv
 
 
@@ -243,6 +243,84 @@ def test_attention_dropout_is_independent_inside_a_key_quad(hip):
             assert abs(joint / (p * p) - 1.0) < 0.05, (a, c, joint)
     across = float((d[..., :-1, 3] * d[..., 1:, 0]).mean())                 # neighbouring quads
     assert abs(across / (p * p) - 1.0) < 0.05, across
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.2])
+def test_attention_packed_sequences_of_any_length(hip, drop_p):
+    """The packed layout the unpadded encoder runs on: sequence b = rows cu[b] .. cu[b+1]-1, lengths that are no multiple
+    of any tile (1 row into a tile, 63 rows, a whole S, a single row, an EMPTY sequence), masked rows in the middle of a
+    sequence (labelled padding positions: queries, never keys). Per sequence against torch on exactly its rows; rows that
+    belong to no sequence are never written; the backward is exact about what a neighbouring sequence's rows (which the
+    tile loads do touch) may contribute: nothing. With dropout: forward / backward replay and the p = 0 limit in mean."""
+    S, NH = 512, 3
+    H = NH * 64
+    lens = [417, 65, 512, 1, 0, 63, 320, 129]
+    B = len(lens)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    T = int(cu[-1]) + 37                                   # trailing rows outside every sequence
+    g = torch.Generator(device="cuda").manual_seed(5)
+    qkv = (torch.randn(T, 3 * H, device="cuda", generator=g) * 1.5).to(torch.bfloat16)
+    dout = torch.randn(T, H, device="cuda", generator=g).to(torch.bfloat16)
+    mask = torch.ones(T, dtype=torch.long)
+    mask[150:167] = 0                                      # sequence 0: 17 masked rows between "text" and "entities"
+    mask[int(cu[6]) + 300: int(cu[6]) + 320] = 0           # sequence 6: a masked tail
+    mask[int(cu[-1]):] = 0
+    mask, cu_d = mask.cuda(), cu.cuda()
+    out, lse = _run_fwd(hip, qkv, mask, B, S, NH, 0.0, 0, cu=cu_d)
+    dqkv = _run_bwd(hip, qkv, mask, out, dout, lse, B, S, NH, 0.0, 0, cu=cu_d)
+    torch.cuda.synchronize()
+    assert bool((out[int(cu[-1]):] == 7.0).all()) and float(dqkv[int(cu[-1]):].abs().max()) == 0.0
+    for b, n in enumerate(lens):
+        if n == 0:
+            continue
+        lo = int(cu[b])
+        rows = slice(lo, lo + n)
+        o_ref, lse_ref, g_ref = _ref(qkv[rows], mask[rows][None], 1, n, NH, dout[rows])
+        torch.testing.assert_close(out[rows].float(), o_ref, rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(lse[b, :, :n], lse_ref[0], rtol=1e-4, atol=2e-3)
+        for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+            e = _relerr(dqkv[rows, sl], g_ref[:, sl])
+            assert e < 2e-2, (b, n, name, e)
+    assert float(dqkv[150:167, H:].abs().max()) == 0.0     # masked rows: no key / value gradient
+    if drop_p > 0:
+        o1, l1 = _run_fwd(hip, qkv, mask, B, S, NH, drop_p, 9, cu=cu_d)
+        o2, _ = _run_fwd(hip, qkv, mask, B, S, NH, drop_p, 9, cu=cu_d)
+        assert torch.equal(o1, o2)
+        live = torch.cat([torch.arange(int(cu[b]), int(cu[b + 1])) for b in range(B)]).cuda()
+        torch.testing.assert_close(torch.nan_to_num(l1), torch.nan_to_num(lse))
+        acc = torch.zeros(T, H, device="cuda")
+        n_s = 48
+        for sd in range(n_s):
+            acc += _run_fwd(hip, qkv, mask, B, S, NH, drop_p, 100 + sd, cu=cu_d)[0].float()
+        assert _relerr((acc / n_s)[live], out[live]) < 0.12
+        g1 = _run_bwd(hip, qkv, mask, o1, dout, l1, B, S, NH, drop_p, 9, cu=cu_d)
+        g2 = _run_bwd(hip, qkv, mask, o1, dout, l1, B, S, NH, drop_p, 9, cu=cu_d)
+        assert torch.equal(g1, g2) and bool(torch.isfinite(g1).all())
+
+
+def test_attention_packed_equals_padded_when_nothing_is_dropped(hip):
+    """cu = [0, S, 2S, ...] and a per-row mask is the padded layout said differently: bitwise the same results."""
+    B, S, NH = 3, 256, 2
+    qkv, dout, mask = _inputs(B, S, NH, 19, True)
+    cu = (torch.arange(B + 1, dtype=torch.int32) * S).cuda()
+    o0, l0 = _run_fwd(hip, qkv, mask, B, S, NH, 0.1, 3)
+    o1, l1 = _run_fwd(hip, qkv, mask.view(-1), B, S, NH, 0.1, 3, cu=cu)
+    assert torch.equal(o0, o1) and torch.equal(l0, l1)
+    g0 = _run_bwd(hip, qkv, mask, o0, dout, l0, B, S, NH, 0.1, 3)
+    g1 = _run_bwd(hip, qkv, mask.view(-1), o0, dout, l0, B, S, NH, 0.1, 3, cu=cu)
+    assert torch.equal(g0, g1)
+
+
+def test_attention_refuses_more_than_4096_keys(hip):
+    """One bit per 64-key tile in a 64-bit word: beyond 4096 keys the launchers refuse (STONK_ESHAPE) instead of dropping
+    tiles silently."""
+    S = 4224
+    qkv = torch.zeros(S, 192, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(hip.StonkHipError):
+        _run_fwd(hip, qkv, None, 1, S, 1)
+    out, lse = _run_fwd(hip, torch.zeros(4096, 192, device="cuda", dtype=torch.bfloat16), None, 1, 4096, 1)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(lse).all())
 
 
 def test_attention_bad_shape(hip):

@@ -9,7 +9,6 @@
 Reference behaviour: DDP through HF Trainer, ref:src/stonkgs/models/stonkgs_pretraining.py:215-223."""
 import json
 import os
-import socket
 import subprocess
 import sys
 
@@ -20,35 +19,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _ranks(n, script, *args, env=None, timeout=300):
+    """Start `n` ranks of a script through stonkgs_amd/launch.py: the test owns every rank's pid (each rank is the leader
+    of its own session and is signalled directly: SIGTERM, then SIGKILL - nothing is left behind on the GPU, and no
+    launcher sits in between that a kill would orphan its workers from), their output goes to files and comes back whole,
+    also when the wall limit ends the job."""
+    from stonkgs_amd.launch import run_ranks
 
-
-def _run_group(cmd, env=None, timeout=300):
-    """Run a launcher in its own process group; on a timeout the WHOLE group (ranks included) is killed, so that no rank
-    is left behind on the GPU."""
-    import signal
-
-    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-    e.update(env or {})
-    proc = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
-    try:
-        out, err = proc.communicate(timeout=timeout)
-    except subprocess.TimeoutExpired:
-        os.killpg(proc.pid, signal.SIGKILL)
-        out, err = proc.communicate()
-        return subprocess.CompletedProcess(cmd, -9, out, "TIMEOUT\n" + err)
-    return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
-
-
-def _torchrun(n, script, *args, env=None, timeout=300):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, script), *args]
-    return _run_group(cmd, env, timeout)
+    return run_ranks(n, [sys.executable, os.path.join(ROOT, script), *args], timeout=timeout, env=env)
 
 
 def test_rccl_path_executes_in_a_one_rank_group(hip):
@@ -78,8 +56,13 @@ def test_rccl_path_executes_in_a_one_rank_group(hip):
         torch.cuda.synchronize()
         return losses, model._store.data.detach().clone(), tr
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    from datetime import timedelta
+
+    from stonkgs_amd.launch import free_port
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()),
+                            timeout=timedelta(seconds=120))
     try:
         l1, p1, tr1 = run(True)
         assert tr1.sync.active and len(tr1.sync.buckets) >= 3 and dist.get_backend() == "nccl"
@@ -97,21 +80,22 @@ def test_rccl_path_executes_in_a_one_rank_group(hip):
 
 
 def test_two_ranks_on_one_gpu_over_gloo(hip):
-    r = _torchrun(2, "tools/dp_check.py", env={"STONK_DIST_BACKEND": "gloo"})
-    assert r.returncode == 0 and "DP2 OK (gloo)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    r = _ranks(2, "tools/dp_check.py", env={"STONK_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0 and "DP2 OK (gloo)" in r.stdout[0], r.tail()
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
 def test_two_ranks_over_rccl(hip):
-    r = _torchrun(2, "tools/dp_check.py")
-    assert r.returncode == 0 and "DP2 OK (nccl)" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    r = _ranks(2, "tools/dp_check.py")
+    assert r.returncode == 0 and "DP2 OK (nccl)" in r.stdout[0], r.tail()
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
 def test_bench_gpus_2_is_a_two_rank_rccl_job(hip):
     """`python bench.py --gpus 2` (no launcher) starts two ranks itself and reports them."""
-    r = _run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
-                    "--no-roofline"], timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--no-roofline"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, STONK_BENCH_WALL_LIMIT="600"))   # (bench.py stops its own ranks at its limit)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 128 and line["config"]["parallelism"] == "dp2"

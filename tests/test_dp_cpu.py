@@ -65,3 +65,49 @@ def test_single_process_is_a_noop():
     s = GradSynchronizer(grad, {"x": 10})
     s.on_segment_done("x")
     assert s.finish() == 1.0 and torch.equal(grad, torch.ones(10))
+
+
+# ---- the rank launcher (stonkgs_amd/launch.py): owned pids, bounded run time, output that survives a kill
+def _probe(mode, **kw):
+    import sys
+
+    from stonkgs_amd.launch import run_ranks
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    return run_ranks(2, [sys.executable, os.path.join(here, "_rank_probe.py"), mode], **kw)
+
+
+def test_launcher_runs_two_gloo_ranks():
+    r = _probe("allreduce", timeout=120)
+    assert r.returncode == 0 and r.codes == [0, 0], r.tail()
+    assert all("sum 3" in o for o in r.stdout)
+    sids = {o.split("sid ")[1].split()[0] for o in r.stdout}
+    assert len(sids) == 2 and str(os.getsid(0)) not in sids      # every rank leads a session of its own
+
+
+def test_launcher_deadline_stops_every_rank_and_keeps_their_output():
+    import time
+
+    t0 = time.time()
+    r = _probe("hang", timeout=3)
+    assert r.timed_out and r.returncode == 124 and time.time() - t0 < 30
+    assert all("about to hang" in e for e in r.stderr)           # what the ranks wrote before the kill came back
+    pids = [int(o.split("pid ")[1].split()[0]) for o in r.stdout]
+    pids.append(int(r.stdout[1].split("grandchild ")[1].split()[0]))
+    time.sleep(0.5)
+    for pid in pids:                                             # ranks AND the grandchild are gone
+        try:
+            os.kill(pid, 0)
+            alive = open(f"/proc/{pid}/stat").read().split()[2] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, pid
+
+
+def test_launcher_stops_the_peers_of_a_dead_rank():
+    import time
+
+    t0 = time.time()
+    r = _probe("die", timeout=120, peer_grace=1.0)
+    assert r.returncode == 7 and not r.timed_out and r.codes[0] == 7 and r.codes[1] != 0
+    assert time.time() - t0 < 30

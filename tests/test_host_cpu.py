@@ -99,7 +99,8 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _hip.lib().stonk_abi_version() == 2
+    assert _hip.lib().stonk_abi_version() == 3
+    assert _hip.lib().stonk_sumsq_workspace_floats() == 1025
     assert _hip.lib().stonk_layernorm_bwd_workspace_floats(32768, 768) == 1024 * 2 * 768   # (no GPU touched: a size query)
     assert _hip.lib().stonk_layernorm_bwd_workspace_floats(0, 768) == 0
 
@@ -109,7 +110,9 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert lib.stonk_gemm_nt_bf16(0, 0, 0, 0, 0, 0, 1, 128, 64, 0, 0, 0, 0, 0, 0, 1.0, 1, 0, 0, 0.0, 0, 0, 0) == -1
     assert lib.stonk_gemm_nt_bf16(16, 64, 16, 64, 16, 128, 1, 128, 64, 0, 0, 0, 0, 0, 0, 1.0, 1, 0, 0, 0.0, 0, 9, 0) == -1   # unknown kernel
     assert lib.stonk_layernorm_fwd(16, 16, 16, 16, 0, 0, 4, 7, 1e-12, 0, 0.0, 0, 0) == -2
-    assert lib.stonk_attention_fwd(16, 16, 16, 192, 0, 16, 64, 0, 1, 1, 100, 64, 0.125, 0.0, 0, 0) == -2
+    assert lib.stonk_attention_fwd(16, 16, 16, 192, 0, 0, 16, 64, 0, 1, 1, 100, 64, 0.125, 0.0, 0, 0) == -2
+    assert lib.stonk_attention_fwd(16, 16, 16, 192, 0, 0, 16, 64, 0, 1, 1, 4224, 64, 0.125, 0.0, 0, 0) == -2    # > 4096 keys: refused
+    assert lib.stonk_attention_fwd(16, 16, 16, 192, 0, 16, 16, 64, 0, 1, 1, 512, 64, 0.125, 0.0, 0, 0) == -1  # packed rows need a mask
     with pytest.raises(_hip.StonkHipError):
         _hip.check(-2, "x")
 
@@ -218,34 +221,35 @@ def test_bench_contract_constants():
 
 
 def test_bench_spawns_ranks_and_refuses_a_mismatched_launcher(monkeypatch):
-    """`bench.py --gpus N` outside a launcher starts N ranks through torch.distributed.run as a child process (the
-    parent never initialises a GPU); inside a launcher whose WORLD_SIZE differs from --gpus it refuses to report."""
+    """`bench.py --gpus N` outside a launcher starts N ranks it owns (stonkgs_amd/launch.py: no GPU touched by the parent,
+    a wall limit, the ranks' exit code relayed); inside a launcher whose WORLD_SIZE differs from --gpus it refuses to report."""
     import importlib
-    import subprocess
     import sys
 
     sys.path.insert(0, ROOT)
     bench = importlib.import_module("bench")
+    launch = importlib.import_module("stonkgs_amd.launch")
     calls = {}
 
-    def fake_run(cmd, env=None, **kw):
-        calls["cmd"], calls["env"] = cmd, env
+    def fake_run_ranks(world, argv, timeout, env=None, relay=False, **kw):
+        calls.update(world=world, argv=list(argv), timeout=timeout, relay=relay)
+        return launch.RankResult(7, False, [""] * world, [""] * world, [7] + [0] * (world - 1))
 
-        class R:
-            returncode = 7
-        return R()
-
-    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(launch, "run_ranks", fake_run_ranks)
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("STONK_DIST_BACKEND", raising=False)
     with pytest.raises(SystemExit) as e:
         bench.main()
-    assert e.value.code == 7   # the child's exit code is relayed
-    cmd = calls["cmd"]
-    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
-    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert e.value.code == 7   # the ranks' exit code is relayed
+    assert calls["world"] == 4 and calls["relay"] and 0 < calls["timeout"] < 3600
+    assert calls["argv"][0] == sys.executable and calls["argv"][1].endswith("bench.py")
+    assert calls["argv"][-4:] == ["--gpus", "4", "--steps", "2"]
+    env = launch.rank_env(2, 4, 12345)
+    assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"], env["MASTER_PORT"]) == \
+        ("2", "2", "4", "127.0.0.1", "12345")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["GLOO_SOCKET_IFNAME"] == "lo"
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     with pytest.raises(SystemExit) as e:   # fewer GPUs than ranks: loud failure, no 1-rank run under an N-GPU label
         bench.main()

@@ -228,7 +228,8 @@ def test_adamw_matches_torch(hip, clip):
         opt.step()
         gg = g.clone()
         nrm = torch.zeros(1, device="cuda")
-        hip.call("stonk_sumsq_f32", hip.ptr(gg), n, hip.ptr(nrm), hip.stream_ptr())
+        ws = torch.zeros(int(hip.lib().stonk_sumsq_workspace_floats()), device="cuda")
+        hip.call("stonk_sumsq_f32", hip.ptr(gg), n, hip.ptr(nrm), hip.ptr(ws), ws.numel(), hip.stream_ptr())
         torch.testing.assert_close(nrm[0], (g.double() ** 2).sum().float(), rtol=1e-5, atol=0)
         hip.call("stonk_adamw_step", hip.ptr(p), hip.ptr(gg), hip.ptr(m), hip.ptr(v), hip.ptr(pb), n, 1e-3, 0.9, 0.999,
                  1e-8, 0.01, 1 - 0.9 ** step, 1 - 0.999 ** step, hip.ptr(nrm), 1.0, 1.0, hip.stream_ptr())
@@ -244,8 +245,26 @@ def test_sumsq_is_bitwise_repeatable(hip):
     n = 50_000_003
     g = _rand((n,), 1.0, 77, torch.float32)
     out = torch.zeros(20, device="cuda")
+    ws = torch.zeros(int(hip.lib().stonk_sumsq_workspace_floats()), device="cuda")
     for i in range(20):
-        hip.call("stonk_sumsq_f32", hip.ptr(g), n, out[i:].data_ptr(), hip.stream_ptr())
+        hip.call("stonk_sumsq_f32", hip.ptr(g), n, out[i:].data_ptr(), hip.ptr(ws), ws.numel(), hip.stream_ptr())
     torch.cuda.synchronize()
     assert (out == out[0]).all(), out.tolist()
     torch.testing.assert_close(out[0], (g.double() ** 2).sum().float(), rtol=1e-5, atol=0)
+    assert int(ws[-1].view(torch.int32).item()) == 0          # the ticket word is left ready for the next launch
+    # two launches in flight on two streams, each with its own workspace (the state used to be library globals, where
+    # they would have shared slots and ticket): both get the bits of the serial launches
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ws2 = torch.zeros_like(ws)
+    g2 = g * 0.5
+    both = torch.zeros(2, 8, device="cuda")
+    torch.cuda.synchronize()
+    for i in range(8):
+        with torch.cuda.stream(s1):
+            hip.call("stonk_sumsq_f32", hip.ptr(g), n, both[0, i:].data_ptr(), hip.ptr(ws), ws.numel(), hip.stream_ptr())
+        with torch.cuda.stream(s2):
+            hip.call("stonk_sumsq_f32", hip.ptr(g2), n, both[1, i:].data_ptr(), hip.ptr(ws2), ws2.numel(), hip.stream_ptr())
+    torch.cuda.synchronize()
+    assert (both[0] == out[0]).all() and (both[1] == both[1, 0]).all()
+    torch.testing.assert_close(both[1, 0], (g2.double() ** 2).sum().float(), rtol=1e-5, atol=0)
+    assert hip.lib().stonk_sumsq_f32(hip.ptr(g), n, out.data_ptr(), hip.ptr(ws), 8, hip.stream_ptr()) == -1   # short workspace

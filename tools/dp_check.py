@@ -3,12 +3,19 @@
   * backend "gloo" (STONK_DIST_BACKEND=gloo): all ranks on GPU 0 - a rehearsal of the multi-GPU step logic on a one-GPU box
     (bucketed all-reduce issued under the weight-gradient stream, optimizer waiting for it, the dynamically scheduled
     dgrad kernel while communication holds CUs).
-Launch (tests/test_dist_gpu.py does):
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/dp_check.py
+Launch: tests/test_dist_gpu.py starts the ranks itself (stonkgs_amd/launch.py: RANK / WORLD_SIZE / MASTER_* in the environment,
+one session per rank, logs in files); `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+--master-port 29533 tools/dp_check.py` works as well.
+A rank that stalls says where: every phase is announced on stderr, rendezvous and collectives carry a 120-s limit (an
+error, not a silent wait), and after STONK_DP_CHECK_DUMP_AFTER seconds (default 200) every thread's Python stack is written
+to stderr - the launcher keeps the ranks' output in files, so it survives the kill that follows.
 Checks: both ranks end with bitwise-identical parameters; they match a single-process run that accumulates the two
 ranks' batches (DDP semantics: mean over ranks of per-rank mean losses) within fp32 round-off of the atomics."""
+import faulthandler
 import os
 import sys
+import time
+from datetime import timedelta
 
 import torch
 import torch.distributed as dist
@@ -28,16 +35,27 @@ def build(seed=0):
     return cfg, STonKGsForPreTraining(cfg, kg_embeddings=table, seed=seed)
 
 
+T0 = time.time()
+
+
+def say(msg):
+    print(f"[dp_check rank {os.environ.get('RANK', '?')} +{time.time() - T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
+    faulthandler.dump_traceback_later(float(os.environ.get("STONK_DP_CHECK_DUMP_AFTER", "200")), exit=False)
     backend = os.environ.get("STONK_DIST_BACKEND", "nccl")
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    limit = timedelta(seconds=120)
+    say(f"rendezvous ({backend}, {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')})")
     if backend == "nccl":
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=limit)
     else:
         torch.cuda.set_device(0)
-        dist.init_process_group(backend)
+        dist.init_process_group(backend, timeout=limit)
     rank, world = dist.get_rank(), dist.get_world_size()
+    say("process group up; building the model")
     B = 32
     cfg, model = build()
     tr = Trainer(model, TrainingArguments(learning_rate=1e-3, max_steps=10, per_device_train_batch_size=B, ddp_bucket_mb=8))
@@ -46,6 +64,7 @@ def main():
     for step in range(2):
         b = synthetic_batch(B, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=100 + 10 * step + rank)
         losses.append(float(tr.training_step(model, b)))
+        say(f"step {step} done, loss {losses[-1]:.4f}")
     model.engine.check_errors()
     model.engine.wait_params()   # the optimizer runs on its own stream
     flat = model._store.data.detach().clone()
@@ -65,6 +84,7 @@ def main():
             if cnt:
                 print(f"  {name}: {cnt} of {n} differ, max {float((gathered[0][off:off+n]-gathered[1][off:off+n]).abs().max()):.3e}", flush=True)
         print("buckets:", tr.sync.buckets, flush=True)
+    say(f"replicas compared: identical = {same}")
     if rank == 0:
         # single process, the same 2 x 2 batches with gradient accumulation over the "ranks"
         cfg2, ref = build()
@@ -81,8 +101,10 @@ def main():
         print(f"ranks identical: {same}; losses {losses}; max |dp - accumulated| = {d:.3e} (param scale {scale:.2f})", flush=True)
         assert same and d < 2e-3, (same, d)
         print(f"DP{world} OK ({backend})", flush=True)
+    say("final barrier")
     dist.barrier()
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":

@@ -79,12 +79,14 @@ int stonk_layernorm_bwd(const void* dy, const void* x, const float* mean, const 
  *   row (b,s>=half) = kg_table[input_ids[b,s]]       (fp32 node2vec table; ids 100/102/103 = LM special vectors)
  * Replaces the Python gather loop, torch.stack/cat and the CPU fp32 round trip of
  * ref:src/stonkgs/models/stonkgs_model.py:182-200 plus BertEmbeddings hf:modeling_bert.py:98-108.
- * An id outside [0, kg_rows) sets bit 0 of *err_flag (the reference raises KeyError at :185). */
+ * An id outside [0, kg_rows) sets bit 0 of *err_flag (the reference raises KeyError at :185).
+ * pos_of_row (nullable) / n_rows: the PACKED layout of stonk_unpad_plan - output row i (i < n_rows) is padded position
+ * pos_of_row[i]; rows whose entry is -1 (the tail up to n_rows) are written as zeros with mean 0, rstd 1. */
 int stonk_joint_embed_ln_fwd(const int64_t* input_ids, const int64_t* token_type_ids, const void* text_hidden,
                              const float* kg_table, const float* pos_emb, const float* type_emb, const float* gamma,
                              const float* beta, void* sum_out, void* y, float* mean, float* rstd, int B, int S,
                              int half, int H, int64_t kg_rows, int type_rows, float eps, int flags, float drop_p,
-                             uint32_t seed, int* err_flag, void* stream);
+                             uint32_t seed, int* err_flag, const int* pos_of_row, int64_t n_rows, void* stream);
 
 /* Frozen LM backbone embeddings: word_emb[input_ids[:, :S]] + pos + type[0] -> LayerNorm -> dropout.
  * Replaces BertEmbeddings of `self.lm_backbone(input_ids[:, :half])`, ref:stonkgs_model.py:178. */
@@ -93,9 +95,24 @@ int stonk_text_embed_ln_fwd(const int64_t* input_ids, int64_t ld_ids, const floa
                             int64_t vocab, float eps, int flags, float drop_p, uint32_t seed, int* err_flag,
                             void* stream);
 
-/* d(position_embeddings) and d(token_type_embeddings) from d(embedding sum) (bf16 [B*S,H]); accumulates. */
+/* d(position_embeddings) and d(token_type_embeddings) from d(embedding sum) (bf16 [B*S,H]); accumulates.
+ * row_of_pos (nullable): packed layout - dx row of padded position p is row_of_pos[p], -1 = dropped (no gradient). */
 int stonk_embed_grad(const void* dx, const int64_t* token_type_ids, float* dpos, float* dtype, int B, int S, int H,
-                     int type_rows, void* stream);
+                     int type_rows, const int* row_of_pos, void* stream);
+
+/* Row plan of the unpadded trainable encoder. A padded text position is never a key, and its output is read only if it
+ * carries a label (the reference labels 15 % of the PADDED half, ref:src/stonkgs/data/indra_for_pretraining.py:33-77) or
+ * is position 0 (the pooler's input): every other padded row can be dropped without changing a loss term or a gradient
+ * of ref:src/stonkgs/models/stonkgs_model.py:204-245. Kept: attention_mask != 0, s == 0, text_labels[b,s] != -100
+ * (s < half), ent_labels[b,s-half] != -100 (labels nullable); a sequence WITHOUT any unmasked key keeps all S positions
+ * (the reference then attends uniformly over them). Outputs (int32 unless stated, device): row_of_pos [B*S] (-1 =
+ * dropped), pos_of_row [B*S] (-1 past the total), seq_offsets [B+1] ([B] = total; the `seq_offsets` of
+ * stonk_attention_*), row_mask int64 [B*S] (attention_mask per packed row, 0 past the total). workspace: device ints,
+ * stonk_unpad_workspace_ints(B) of them. */
+int64_t stonk_unpad_workspace_ints(int B);
+int stonk_unpad_plan(const int64_t* attention_mask, const int64_t* text_labels, const int64_t* ent_labels, int B, int S,
+                     int half, int* row_of_pos, int* pos_of_row, int* seq_offsets, int64_t* row_mask, int* workspace,
+                     int64_t ws_ints, void* stream);
 
 /* Fused attention, head_dim 64, S % 128 == 0, S <= 4096: out = dropout(softmax(q k^T * scale + mask)) v.
  * q/k/v: column slices of the [T, 3H] projection (row stride ld), head h at columns h*64..; attention_mask int64
@@ -148,10 +165,11 @@ int stonk_assemble_rows(const int64_t* text_ids, const int64_t* text_attention, 
                         int64_t sep_id, float negative_rate, uint32_t seed, int* err_flag, void* stream);
 
 /* Labelled-row compaction for the MLM / ELM heads (labels != -100), count kept on the device.
- * rows_out[i] = b*S + offset + pos of the i-th labelled position. Semantics of nn.CrossEntropyLoss(ignore_index
- * =-100) at ref:stonkgs_model.py:229-240. */
+ * rows_out[i] = b*S + offset + pos of the i-th labelled position - or, with row_of_pos (nullable; packed layout of
+ * stonk_unpad_plan), that position's packed row. Semantics of nn.CrossEntropyLoss(ignore_index=-100) at
+ * ref:stonkgs_model.py:229-240. */
 int stonk_label_compact(const int64_t* labels, int64_t n, int half, int S, int offset, int* rows_out, int* targets_out,
-                        int* count_out, void* stream);
+                        int* count_out, const int* row_of_pos, void* stream);
 int stonk_gather_rows_bf16(const void* src, int64_t ld_src, const int* rows, const int* count_dev, void* dst,
                            int64_t ld_dst, int cols, int64_t cap, void* stream);
 int stonk_scatter_rows_bf16(const void* src, int64_t ld_src, const int* rows, const int* count_dev, void* dst,

@@ -40,10 +40,11 @@ _SIGNATURES = {
     "stonk_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _u32, _f32, _u32,
                             _vp, _i64, _vp],
     "stonk_joint_embed_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
-                                 _i64, _i32, _f32, _i32, _f32, _u32, _vp, _vp],
+                                 _i64, _i32, _f32, _i32, _f32, _u32, _vp, _vp, _i64, _vp],
+    "stonk_unpad_plan": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "stonk_text_embed_ln_fwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _f32, _i32, _f32,
                                 _u32, _vp, _vp],
-    "stonk_embed_grad": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "stonk_embed_grad": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "stonk_attention_fwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u32, _vp],
     "stonk_attention_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i32,
                             _i32, _i32, _i32, _f32, _f32, _u32, _vp],
@@ -54,7 +55,7 @@ _SIGNATURES = {
     "stonk_mlm_mask": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _u32, _vp],
     "stonk_assemble_rows": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _f32, _u32, _vp,
                             _vp],
-    "stonk_label_compact": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "stonk_label_compact": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "stonk_gather_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i64, _vp],
     "stonk_scatter_rows_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp],
     "stonk_scatter_rows_f32_to_bf16": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp],
@@ -111,13 +112,15 @@ def lib():
         handle.stonk_layernorm_bwd_workspace_floats.restype = C.c_int64
         handle.stonk_sumsq_workspace_floats.argtypes = []
         handle.stonk_sumsq_workspace_floats.restype = C.c_int64
+        handle.stonk_unpad_workspace_ints.argtypes = [_i32]
+        handle.stonk_unpad_workspace_ints.restype = C.c_int64
         _lib = handle
     return _lib
 
 
 def exported_symbols():
     return sorted(list(_SIGNATURES) + ["stonk_abi_version", "stonk_layernorm_bwd_workspace_floats",
-                                     "stonk_sumsq_workspace_floats"])
+                                     "stonk_sumsq_workspace_floats", "stonk_unpad_workspace_ints"])
 
 
 def check(status: int, name: str) -> None:

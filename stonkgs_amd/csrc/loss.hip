@@ -15,7 +15,8 @@ namespace {
 // rows_out[i] = token row (b*S + offset + pos) of the i-th labelled position, targets_out[i] = its label.
 __global__ __launch_bounds__(1024) void label_compact_kernel(const long* __restrict__ labels, long n, int half, int S,
                                                              int offset, int* __restrict__ rows_out,
-                                                             int* __restrict__ targets_out, int* __restrict__ count_out) {
+                                                             int* __restrict__ targets_out, int* __restrict__ count_out,
+                                                             const int* __restrict__ row_of_pos) {
   __shared__ int wsum[16];
   __shared__ int base;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -35,7 +36,8 @@ __global__ __launch_bounds__(1024) void label_compact_kernel(const long* __restr
     if (flag) {
       const int dst = b0 + woff + prefix;
       const long b = i / half;
-      rows_out[dst] = (int)(b * S + offset + (i - b * half));
+      const long pos = b * S + offset + (i - b * half);
+      rows_out[dst] = row_of_pos ? row_of_pos[pos] : (int)pos;   // packed layout: a labelled position always has a row
       targets_out[dst] = (int)lab;
     }
     __syncthreads();
@@ -267,11 +269,11 @@ __global__ void loss_finalize_kernel(const float* text_sum, const int* text_cnt,
 }  // namespace
 
 extern "C" int stonk_label_compact(const int64_t* labels, int64_t n, int half, int S, int offset, int* rows_out,
-                                   int* targets_out, int* count_out, void* stream) {
+                                   int* targets_out, int* count_out, const int* row_of_pos, void* stream) {
   STONK_CHECK_ARG(labels && rows_out && targets_out && count_out, STONK_EINVAL);
   STONK_CHECK_ARG(n >= 0 && half > 0 && S >= half && offset >= 0, STONK_ESHAPE);
   hipLaunchKernelGGL(label_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const long*)labels, (long)n,
-                     half, S, offset, rows_out, targets_out, count_out);
+                     half, S, offset, rows_out, targets_out, count_out, row_of_pos);
   return stonk_launch_status();
 }
 

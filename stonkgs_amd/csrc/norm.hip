@@ -18,6 +18,14 @@ struct RowRegs {
 };
 
 template <int CPL>
+__device__ __forceinline__ void zero_row(RowRegs<CPL>& r) {
+#pragma unroll
+  for (int i = 0; i < CPL; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
+}
+
+template <int CPL>
 __device__ __forceinline__ void load_bf16_row(const bf16* row, int nch, int lane, RowRegs<CPL>& r) {
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
@@ -533,24 +541,40 @@ __global__ __launch_bounds__(256) void joint_embed_ln_kernel(
     const float* __restrict__ kg_table, const float* __restrict__ pos_emb, const float* __restrict__ type_emb,
     const float* __restrict__ gamma, const float* __restrict__ beta, bf16* __restrict__ sum_out, bf16* __restrict__ y,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, int B, int S, int half, int H, long kg_rows,
-    int type_rows, float eps, int flags, uint32_t thr32, float dscale, uint32_t seed, int* __restrict__ err) {
+    int type_rows, float eps, int flags, uint32_t thr32, float dscale, uint32_t seed, int* __restrict__ err,
+    const int* __restrict__ pos_of_row, long n_rows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = H >> 3;
-  const long rows = (long)B * S;
+  const long rows = pos_of_row ? n_rows : (long)B * S;
   for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
-    const int b = (int)(row / S), s = (int)(row - (long)b * S);
+    // packed layout (stonk_unpad_plan): output row `row` is padded position pos_of_row[row]; a row that belongs to no
+    // position (the tail up to the launch's row count) is written as zeros - finite for everything downstream, and with
+    // zero gradient coming back
+    const long pos = pos_of_row ? pos_of_row[row] : row;
+    if (pos < 0) {
+      RowRegs<CPL> z;
+      zero_row<CPL>(z);
+      if (sum_out) store_bf16_row<CPL>(sum_out + row * H, nch, lane, z);
+      store_bf16_row<CPL>(y + row * H, nch, lane, z);
+      if (lane == 0 && mean_out) {
+        mean_out[row] = 0.f;
+        rstd_out[row] = 1.f;
+      }
+      continue;
+    }
+    const int b = (int)(pos / S), s = (int)(pos - (long)b * S);
     RowRegs<CPL> r;
     if (s < half) {
       load_bf16_row<CPL>(text_hidden + ((long)b * half + s) * H, nch, lane, r);
     } else {
-      long id = input_ids[row];
+      long id = input_ids[pos];
       if (id < 0 || id >= kg_rows) {  // the reference raises KeyError here (stonkgs_model.py:185)
         if (lane == 0) atomicOr(err, 1);
         id = 0;
       }
       load_f32_row<CPL>(kg_table + id * H, nch, lane, r);
     }
-    long tt = token_type_ids ? token_type_ids[row] : 0;
+    long tt = token_type_ids ? token_type_ids[pos] : 0;
     if (tt < 0 || tt >= type_rows) {
       if (lane == 0) atomicOr(err, 2);
       tt = 0;
@@ -605,15 +629,18 @@ __global__ __launch_bounds__(256) void text_embed_ln_kernel(const long* __restri
 __global__ __launch_bounds__(256) void embed_grad_kernel(const bf16* __restrict__ dx,
                                                          const long* __restrict__ token_type_ids,
                                                          float* __restrict__ dpos, float* __restrict__ dtype, int B,
-                                                         int S, int H, int type_rows) {
+                                                         int S, int H, int type_rows,
+                                                         const int* __restrict__ row_of_pos) {
   const int s = blockIdx.x;
   for (int col = threadIdx.x; col < H; col += blockDim.x) {
     float accp = 0.f, t0 = 0.f, t1 = 0.f;
     for (int b = 0; b < B; ++b) {
-      const long row = (long)b * S + s;
+      const long pos = (long)b * S + s;
+      const long row = row_of_pos ? row_of_pos[pos] : pos;   // packed layout: a dropped position has no row, no gradient
+      if (row < 0) continue;
       const float v = (float)dx[row * H + col];
       accp += v;
-      const long tt = token_type_ids ? token_type_ids[row] : 0;
+      const long tt = token_type_ids ? token_type_ids[pos] : 0;
       if (tt == 0) t0 += v;
       else if (tt == 1) t1 += v;
     }
@@ -723,18 +750,22 @@ extern "C" int stonk_joint_embed_ln_fwd(const int64_t* input_ids, const int64_t*
                                         const float* type_emb, const float* gamma, const float* beta, void* sum_out,
                                         void* y, float* mean, float* rstd, int B, int S, int half, int H,
                                         int64_t kg_rows, int type_rows, float eps, int flags, float drop_p,
-                                        uint32_t seed, int* err_flag, void* stream) {
+                                        uint32_t seed, int* err_flag, const int* pos_of_row, int64_t n_rows,
+                                        void* stream) {
   STONK_CHECK_ARG(input_ids && text_hidden && kg_table && pos_emb && type_emb && gamma && beta && y && err_flag,
                   STONK_EINVAL);
   STONK_CHECK_ARG(B >= 0 && S > 0 && half >= 0 && half <= S && H > 0 && H % 8 == 0 && H <= 4096, STONK_ESHAPE);
   STONK_CHECK_ARG(kg_rows > 0 && type_rows > 0, STONK_ESHAPE);
+  STONK_CHECK_ARG(!pos_of_row || (n_rows >= 0 && n_rows <= (long)B * S), STONK_ESHAPE);
   if (B == 0) return STONK_OK;
-  const long rows = (long)B * S;
+  const long rows = pos_of_row ? (long)n_rows : (long)B * S;
+  if (rows == 0) return STONK_OK;
   LN_DISPATCH(H, hipLaunchKernelGGL((joint_embed_ln_kernel<CPL>), dim3(ln_grid(rows)), dim3(256), 0,
                                     (hipStream_t)stream, (const long*)input_ids, (const long*)token_type_ids,
                                     (const bf16*)text_hidden, kg_table, pos_emb, type_emb, gamma, beta,
                                     (bf16*)sum_out, (bf16*)y, mean, rstd, B, S, half, H, (long)kg_rows, type_rows, eps,
-                                    flags, stonk_drop_thr32(drop_p), 1.f / (1.f - drop_p), stonk_seed_mix(seed), err_flag));
+                                    flags, stonk_drop_thr32(drop_p), 1.f / (1.f - drop_p), stonk_seed_mix(seed), err_flag,
+                                    pos_of_row, (long)n_rows));
   return stonk_launch_status();
 }
 
@@ -754,11 +785,11 @@ extern "C" int stonk_text_embed_ln_fwd(const int64_t* input_ids, int64_t ld_ids,
 }
 
 extern "C" int stonk_embed_grad(const void* dx, const int64_t* token_type_ids, float* dpos, float* dtype, int B, int S,
-                                int H, int type_rows, void* stream) {
+                                int H, int type_rows, const int* row_of_pos, void* stream) {
   STONK_CHECK_ARG(dx && dpos && dtype, STONK_EINVAL);
   STONK_CHECK_ARG(B >= 0 && S > 0 && H > 0 && type_rows >= 1, STONK_ESHAPE);
   if (B == 0) return STONK_OK;
   hipLaunchKernelGGL(embed_grad_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, (const bf16*)dx,
-                     (const long*)token_type_ids, dpos, dtype, B, S, H, type_rows);
+                     (const long*)token_type_ids, dpos, dtype, B, S, H, type_rows, row_of_pos);
   return stonk_launch_status();
 }

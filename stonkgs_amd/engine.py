@@ -96,6 +96,14 @@ class Engine:
         # "dgrad_gelu", "dgrad_resid", "dgrad_attn_out", "dgrad_head" -> hip.GEMM_*.
         self.kernel_for: Dict[str, int] = {}
         self.f16_logits = True      # label-sparse decoder logits in fp16 (False: fp32, 4 more bytes of HBM traffic per logit)
+        # Unpadded trainable encoder (csrc/unpad.hip): rows that are neither live keys, nor labelled, nor position 0 are
+        # dropped before the embeddings LayerNorm - no loss term and no gradient reads them - and every per-row kernel,
+        # GEMM and the attention run on the packed rows. Used by the training paths that hand out neither hidden states
+        # nor dense logits (`forward_backward`, `forward(..., return_dict=False)` in training mode); costs one host wait
+        # per step for the packed row count, taken while the frozen backbone's forward is already queued.
+        self.unpad = True
+        self.rows_executed = [0, 0, 0]   # packed rows run, padded rows they stand for, steps (bench: executed FLOPs)
+        self._plan_host: Optional[torch.Tensor] = None
         self._wstream: Optional[torch.cuda.Stream] = None
         # The optimizer (grad-norm, AdamW, W^T refresh: ~2 ms of HBM-bound work) runs on a third stream; the next step's
         # frozen-backbone forward reads none of what it writes and starts beside it. `wait_params()` orders the current
@@ -284,43 +292,49 @@ class Engine:
         return raw, len(entries), first
 
     # ------------------------------------------------------------------ one BERT layer
-    def layer_fwd(self, S: FlatStore, prefix: str, x, B, seq, mask, p_hid, p_att, lidx, save: Optional[dict]):
+    def layer_fwd(self, S: FlatStore, prefix: str, x, B, seq, mask, p_hid, p_att, lidx, save: Optional[dict],
+                  T: Optional[int] = None, cu=None):
+        """One BERT layer on T rows. Padded layout: T = B * seq, `mask` = attention_mask [B, seq]. Packed layout (`cu` =
+        sequence offsets of stonk_unpad_plan): T = the packed row count rounded up to 64, `mask` = one word per row."""
         cfg = self.cfg
         H, I, NH = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
-        T = B * seq
+        cap = B * seq
+        T = cap if T is None else T
         st = hip.stream_ptr()
         tag = prefix if save is not None else "tmp"
         w = S.bf16_view
         f = S.view
-        qkv = self.buf(f"{tag}.qkv", (T, 3 * H))
+        qkv = self.buf(f"{tag}.qkv", (cap, 3 * H))
         self.gemm(x, w(prefix + ".attention.self.qkv.weight"), qkv, T, 3 * H, H, flags=hip.EPI_BIAS,
                   bias=f(prefix + ".attention.self.qkv.bias"), kernel=self._kernel("qkv"))
-        ctx = self.buf(f"{tag}.ctx", (T, H))
+        # (zeroed when allocated: in the packed layout the rows between the last sequence and T are never written by the
+        # attention kernel and must stay finite for the projections that run over them)
+        ctx = self.buf(f"{tag}.ctx", (cap, H), zero=True)
         lse = self.buf(f"{tag}.lse", (B, NH, seq), F32)
         hip.call("stonk_attention_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H,
-                 hip.ptr(mask), ctx.data_ptr(), H, lse.data_ptr(), B, NH, seq, 64, 1.0 / math.sqrt(64.0), p_att,
-                 self.seed(lidx, 1), st)
-        s1 = self.buf(f"{tag}.s1", (T, H))
+                 hip.ptr(mask), hip.ptr(cu), ctx.data_ptr(), H, lse.data_ptr(), B, NH, seq, 64, 1.0 / math.sqrt(64.0),
+                 p_att, self.seed(lidx, 1), st)
+        s1 = self.buf(f"{tag}.s1", (cap, H))
         fl = hip.EPI_BIAS | hip.EPI_RESID | (hip.EPI_DROPOUT if p_hid > 0 else 0)
         self.gemm(ctx, w(prefix + ".attention.output.dense.weight"), s1, T, H, H, flags=fl,
                   bias=f(prefix + ".attention.output.dense.bias"), resid=x, drop_p=p_hid, seed=self.seed(lidx, 2),
                   kernel=self._kernel("attn_out"))
-        h1 = self.buf(f"{tag}.h1", (T, H))
-        st1 = self.buf(f"{tag}.st1", (2, T), F32)
+        h1 = self.buf(f"{tag}.h1", (cap, H))
+        st1 = self.buf(f"{tag}.st1", (2, cap), F32)
         hip.call("stonk_layernorm_fwd", s1.data_ptr(), f(prefix + ".attention.output.LayerNorm.weight").data_ptr(),
                  f(prefix + ".attention.output.LayerNorm.bias").data_ptr(), h1.data_ptr(), st1[0].data_ptr(),
                  st1[1].data_ptr(), T, H, cfg.layer_norm_eps, 0, 0.0, 0, st)
-        g = self.buf(f"{tag}.g", (T, I))
-        u = self.buf(f"{tag}.u", (T, I)) if save is not None else None
+        g = self.buf(f"{tag}.g", (cap, I))
+        u = self.buf(f"{tag}.u", (cap, I)) if save is not None else None
         fl = hip.EPI_BIAS | hip.EPI_GELU | ((hip.EPI_SAVE_PREACT | hip.EPI_AUX_GRAD) if save is not None else 0)
         self.gemm(h1, w(prefix + ".intermediate.dense.weight"), g, T, I, H, flags=fl,
                   bias=f(prefix + ".intermediate.dense.bias"), aux=u, kernel=self._kernel("ffn_up"))
-        s2 = self.buf(f"{tag}.s2", (T, H))
+        s2 = self.buf(f"{tag}.s2", (cap, H))
         fl = hip.EPI_BIAS | hip.EPI_RESID | (hip.EPI_DROPOUT if p_hid > 0 else 0)
         self.gemm(g, w(prefix + ".output.dense.weight"), s2, T, H, I, flags=fl, bias=f(prefix + ".output.dense.bias"),
                   resid=h1, drop_p=p_hid, seed=self.seed(lidx, 3), kernel=self._kernel("ffn_down"))
-        y = self.buf(f"{prefix}.y" if save is not None else f"tmp.y{lidx & 1}", (T, H))
-        st2 = self.buf(f"{tag}.st2", (2, T), F32)
+        y = self.buf(f"{prefix}.y" if save is not None else f"tmp.y{lidx & 1}", (cap, H))
+        st2 = self.buf(f"{tag}.st2", (2, cap), F32)
         hip.call("stonk_layernorm_fwd", s2.data_ptr(), f(prefix + ".output.LayerNorm.weight").data_ptr(),
                  f(prefix + ".output.LayerNorm.bias").data_ptr(), y.data_ptr(), st2[0].data_ptr(), st2[1].data_ptr(), T,
                  H, cfg.layer_norm_eps, 0, 0.0, 0, st)
@@ -328,11 +342,14 @@ class Engine:
             save[prefix] = dict(x=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, h1=h1, st1=st1, g=g, u=u, s2=s2, st2=st2)
         return y
 
-    def layer_bwd(self, prefix: str, dy, B, seq, mask, p_hid, p_att, lidx, sv):
-        """dy: bf16 [T,H] gradient of the layer output. Returns the gradient of the layer input."""
+    def layer_bwd(self, prefix: str, dy, B, seq, mask, p_hid, p_att, lidx, sv, T: Optional[int] = None, cu=None,
+                  rows: Optional[int] = None):
+        """dy: bf16 [T,H] gradient of the layer output. Returns the gradient of the layer input. Packed layout: `cu`,
+        per-row `mask`, T = packed rows rounded up to 64, `rows` = the packed rows that belong to a sequence."""
         cfg = self.cfg
         H, I, NH = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
-        T = B * seq
+        cap = B * seq
+        T = cap if T is None else T
         st = hip.stream_ptr()
         P = self.P
         g_ = P.grad_view
@@ -345,8 +362,8 @@ class Engine:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
         # ---- LN2 backward: ds2 (residual branch) and df (through the FFN-output dropout)
-        ds2 = self.buf(f"b.ds2.{par}", (T, H))
-        df = self.buf(f"b.df.{par}", (T, H)) if p_hid > 0 else None
+        ds2 = self.buf(f"b.ds2.{par}", (cap, H))
+        df = self.buf(f"b.df.{par}", (cap, H)) if p_hid > 0 else None
         hip.call("stonk_layernorm_bwd", dy.data_ptr(), sv["s2"].data_ptr(), sv["st2"][0].data_ptr(),
                  sv["st2"][1].data_ptr(), f(prefix + ".output.LayerNorm.weight").data_ptr(), ds2.data_ptr(), hip.ptr(df),
                  g_(prefix + ".output.LayerNorm.weight").data_ptr(), g_(prefix + ".output.LayerNorm.bias").data_ptr(),
@@ -355,18 +372,18 @@ class Engine:
             df = ds2
         # ---- FFN down: wgrad, bias grad, dgrad fused with GELU'
         self.wgrad(df, sv["g"], g_(prefix + ".output.dense.weight"), g_(prefix + ".output.dense.bias"), H, I, T)
-        du = self.buf(f"b.du.{par}", (T, I))
+        du = self.buf(f"b.du.{par}", (cap, I))
         self.gemm(df, wt[prefix + ".output.dense.weight"], du, T, I, H, flags=hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD,
                   aux=sv["u"], kernel=self._kernel("dgrad_gelu", True))
         # ---- FFN up
         self.wgrad(du, sv["h1"], g_(prefix + ".intermediate.dense.weight"), g_(prefix + ".intermediate.dense.bias"), I, H,
                    T)
-        dh1 = self.buf("b.dh1", (T, H))
+        dh1 = self.buf("b.dh1", (cap, H))
         self.gemm(du, wt[prefix + ".intermediate.dense.weight"], dh1, T, H, I, flags=hip.EPI_RESID, resid=ds2,
                   kernel=self._kernel("dgrad_resid", True))
         # ---- LN1 backward
-        ds1 = self.buf(f"b.ds1.{par}", (T, H))
-        da = self.buf(f"b.da.{par}", (T, H)) if p_hid > 0 else None
+        ds1 = self.buf(f"b.ds1.{par}", (cap, H))
+        da = self.buf(f"b.da.{par}", (cap, H)) if p_hid > 0 else None
         hip.call("stonk_layernorm_bwd", dh1.data_ptr(), sv["s1"].data_ptr(), sv["st1"][0].data_ptr(),
                  sv["st1"][1].data_ptr(), f(prefix + ".attention.output.LayerNorm.weight").data_ptr(), ds1.data_ptr(),
                  hip.ptr(da), g_(prefix + ".attention.output.LayerNorm.weight").data_ptr(),
@@ -377,21 +394,25 @@ class Engine:
         # ---- attention output projection
         self.wgrad(da, sv["ctx"], g_(prefix + ".attention.output.dense.weight"),
                    g_(prefix + ".attention.output.dense.bias"), H, H, T)
-        dctx = self.buf("b.dctx", (T, H))
+        dctx = self.buf("b.dctx", (cap, H))
         self.gemm(da, wt[prefix + ".attention.output.dense.weight"], dctx, T, H, H,
                   kernel=self._kernel("dgrad_attn_out", True))
         # ---- attention core
         qkv = sv["qkv"]
-        dqkv = self.buf(f"b.dqkv.{par}", (T, 3 * H))
+        dqkv = self.buf(f"b.dqkv.{par}", (cap, 3 * H))
         delta = self.buf("b.delta", (B, NH, seq), F32)
+        if cu is not None and rows is not None and rows < T:
+            # the rows between the last sequence and T are not the attention kernel's to write, and the weight gradient
+            # below contracts over all T rows: what an earlier step left there must not reach dW
+            dqkv[rows:T].zero_()
         hip.call("stonk_attention_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H,
-                 hip.ptr(mask), sv["ctx"].data_ptr(), H, dctx.data_ptr(), H, sv["lse"].data_ptr(), delta.data_ptr(),
+                 hip.ptr(mask), hip.ptr(cu), sv["ctx"].data_ptr(), H, dctx.data_ptr(), H, sv["lse"].data_ptr(), delta.data_ptr(),
                  dqkv.data_ptr(), dqkv.data_ptr() + 2 * H, 3 * H, dqkv.data_ptr() + 4 * H, B, NH, seq, 64,
                  1.0 / math.sqrt(64.0), p_att, self.seed(lidx, 1), st)
         # ---- QKV projection
         self.wgrad(dqkv, sv["x"], g_(prefix + ".attention.self.qkv.weight"), g_(prefix + ".attention.self.qkv.bias"),
                    3 * H, H, T)
-        dx = self.buf(f"b.dx{lidx & 1}", (T, H))
+        dx = self.buf(f"b.dx{lidx & 1}", (cap, H))
         self.gemm(dqkv, wt[prefix + ".attention.self.qkv.weight"], dx, T, H, 3 * H, flags=hip.EPI_RESID, resid=ds1,
                   kernel=self._kernel("dgrad_resid", True))
         if self._wstream is not None and self.overlap_wgrad:
@@ -431,77 +452,128 @@ class Engine:
         return {102: out[0].clone(), 103: out[1].clone(), 100: out[2].clone()}
 
     # ------------------------------------------------------------------ forward
-    def encode(self, input_ids, attention_mask, token_type_ids, training: bool, save: dict):
+    def _plan_rows(self, attention_mask, mlm_labels, ent_labels, B, S, half):
+        """Launch the row plan of the unpadded encoder (csrc/unpad.hip) on the current stream and start the copy of the
+        packed row count to the host; returns (plan dict, event). The caller queues the frozen backbone's forward - which
+        does not depend on the plan - and only then waits for the event, so the GPU has work while the host learns the
+        count."""
+        n = B * S
+        row_of_pos = self.buf("u.row_of_pos", (n,), I32)
+        pos_of_row = self.buf("u.pos_of_row", (n,), I32)
+        cu = self.buf("u.cu", (B + 1,), I32)
+        row_mask = self.buf("u.row_mask", (n,), torch.int64)
+        ws = self.buf("u.ws", (int(hip.lib().stonk_unpad_workspace_ints(B)),), I32)
+        hip.call("stonk_unpad_plan", attention_mask.data_ptr(), hip.ptr(mlm_labels), hip.ptr(ent_labels), B, S, half,
+                 row_of_pos.data_ptr(), pos_of_row.data_ptr(), cu.data_ptr(), row_mask.data_ptr(), ws.data_ptr(),
+                 ws.numel(), hip.stream_ptr())
+        if self._plan_host is None:
+            self._plan_host = torch.empty(1, dtype=I32).pin_memory()
+        self._plan_host.copy_(cu[B:B + 1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return dict(row_of_pos=row_of_pos, pos_of_row=pos_of_row, cu=cu, row_mask=row_mask), ev
+
+    def encode(self, input_ids, attention_mask, token_type_ids, training: bool, save: dict, unpad_labels=None):
         """F1-F4: frozen backbone, KG gather + embeddings LayerNorm, encoder layers, pooler. Shared by the pre-training
-        and the sequence-classification models (ref:stonkgs_model.py:178-212, ref:stonkgs_finetuning.py:277-310)."""
+        and the sequence-classification models (ref:stonkgs_model.py:178-212, ref:stonkgs_finetuning.py:277-310).
+        `unpad_labels`: None = padded layout (every position a row: callers that hand out hidden states or dense
+        logits); a (text_labels, entity_labels) pair (either may be None) = packed layout, see `Engine.unpad`."""
         cfg = self.cfg
         H, S, half = cfg.hidden_size, cfg.max_position_embeddings, cfg.half_length
         B = input_ids.shape[0]
-        T = B * S
+        cap = B * S
         st = hip.stream_ptr()
         P = self.P
         f = P.view
         self.seed_base += 1
         p_hid = cfg.hidden_dropout_prob if training else 0.0
         p_att = cfg.attention_probs_dropout_prob if training else 0.0
-        # F1 frozen backbone (no attention mask: quirk Q5)
+        plan = ev = None
+        if unpad_labels is not None and attention_mask is not None and self.unpad and B > 0:
+            plan, ev = self._plan_rows(attention_mask, unpad_labels[0], unpad_labels[1], B, S, half)
+        # F1 frozen backbone (no attention mask: quirk Q5; always padded - its padding positions ARE attended)
         text_hidden = self.backbone_fwd(input_ids, S, B, half, training)
         self.wait_params()   # everything above read frozen weights only; from here on the trainable ones
+        T, rows, cu, mask = cap, cap, None, attention_mask
+        if plan is not None:
+            ev.synchronize()                       # (the backbone's launches are queued: the GPU is not waiting for us)
+            rows = int(self._plan_host[0])
+            T = min(cap, (rows + 63) // 64 * 64)   # whole 64-row K tiles for the weight gradients; the tail rows are zeros
+            cu, mask = plan["cu"], plan["row_mask"]
+        self.rows_executed[0] += T
+        self.rows_executed[1] += cap
+        self.rows_executed[2] += 1
         # F2 gather + concat + embeddings LayerNorm
-        sum0 = self.buf("e.sum0", (T, H))
-        x = self.buf("e.x0", (T, H))
-        st0 = self.buf("e.st0", (2, T), F32)
+        sum0 = self.buf("e.sum0", (cap, H))
+        x = self.buf("e.x0", (cap, H))
+        st0 = self.buf("e.st0", (2, cap), F32)
         hip.call("stonk_joint_embed_ln_fwd", input_ids.data_ptr(), hip.ptr(token_type_ids), text_hidden.data_ptr(),
                  self.kg_table.data_ptr(), f("bert.embeddings.position_embeddings.weight").data_ptr(),
                  f("bert.embeddings.token_type_embeddings.weight").data_ptr(),
                  f("bert.embeddings.LayerNorm.weight").data_ptr(), f("bert.embeddings.LayerNorm.bias").data_ptr(),
                  sum0.data_ptr(), x.data_ptr(), st0[0].data_ptr(), st0[1].data_ptr(), B, S, half, H,
                  self.kg_table.shape[0], cfg.type_vocab_size, cfg.layer_norm_eps, hip.LN_DROPOUT if p_hid > 0 else 0,
-                 p_hid, self.seed(200, 0), self.err.data_ptr(), st)
+                 p_hid, self.seed(200, 0), self.err.data_ptr(), 0 if plan is None else plan["pos_of_row"].data_ptr(),
+                 T if plan is not None else 0, st)
         # F3 encoder
         span = self._span_begin()
         for i in range(cfg.num_hidden_layers):
-            x = self.layer_fwd(P, f"bert.encoder.layer.{i}", x, B, S, attention_mask, p_hid, p_att, i, save)
+            x = self.layer_fwd(P, f"bert.encoder.layer.{i}", x, B, S, mask, p_hid, p_att, i, save, T=T, cu=cu)
         self._span_end("encoder_fwd", span)
         seq_out = x
-        # F4 pooler (fp32 master weights)
+        # F4 pooler (fp32 master weights) on position 0 of every sequence
         pooled = self.buf("h.pooled", (B, H), F32)
-        hip.call("stonk_small_linear_fwd", seq_out.data_ptr(), S * H, f("bert.pooler.dense.weight").data_ptr(),
+        if plan is None:
+            first, ld_first = seq_out, S * H
+        else:   # packed: position 0 of sequence b is row cu[b]
+            nb = self.buf("u.nb", (1,), I32)
+            nb.fill_(B)
+            first, ld_first = self.buf("h.first", ((B + 127) // 128 * 128, H)), H
+            hip.call("stonk_gather_rows_bf16", seq_out.data_ptr(), H, cu.data_ptr(), nb.data_ptr(), first.data_ptr(), H, H,
+                     first.shape[0], st)
+        hip.call("stonk_small_linear_fwd", first.data_ptr(), ld_first, f("bert.pooler.dense.weight").data_ptr(),
                  f("bert.pooler.dense.bias").data_ptr(), pooled.data_ptr(), B, H, H, hip.SMALL_TANH, st)
         if save is not None:   # (None: forward-only callers - embedding extraction, batched inference)
-            save.update(B=B, attention_mask=attention_mask, token_type_ids=token_type_ids, sum0=sum0, st0=st0,
-                        seq_out=seq_out, pooled=pooled, p_hid=p_hid, p_att=p_att)
+            save.update(B=B, attention_mask=mask, token_type_ids=token_type_ids, sum0=sum0, st0=st0,
+                        seq_out=seq_out, pooled=pooled, p_hid=p_hid, p_att=p_att, T=T, rows=rows, plan=plan,
+                        first=first, ld_first=ld_first)
         return seq_out, pooled
 
     def forward(self, input_ids, attention_mask, token_type_ids, mlm_labels, ent_labels, nsp_labels, training: bool,
-                dense_logits: bool, need_backward: bool):
+                dense_logits: bool, need_backward: bool, want_hidden: bool = True):
+        """`want_hidden=False` (with labels, without dense logits): nobody will read `hidden_states`, so the trainable
+        encoder may run on the packed rows (`Engine.unpad`); `hidden_states` is then None."""
         cfg = self.cfg
         H, S, half = cfg.hidden_size, cfg.max_position_embeddings, cfg.half_length
         B = input_ids.shape[0]
-        T = B * S
+        cap_rows = B * S
         st = hip.stream_ptr()
         P = self.P
         f, w = P.view, P.bf16_view
         save: dict = {}
-        seq_out, pooled = self.encode(input_ids, attention_mask, token_type_ids, training, save)
+        have_labels = mlm_labels is not None and ent_labels is not None and nsp_labels is not None
+        packed = have_labels and not dense_logits and not want_hidden
+        seq_out, pooled = self.encode(input_ids, attention_mask, token_type_ids, training, save,
+                                      (mlm_labels, ent_labels) if packed else None)
+        T, plan = save["T"], save["plan"]
+        row_of_pos = None if plan is None else plan["row_of_pos"]
         nsp = self.buf("h.nsp", (B, 2), F32)
         hip.call("stonk_small_linear_fwd", pooled.data_ptr(), H, f("cls.seq_relationship.weight").data_ptr(),
                  f("cls.seq_relationship.bias").data_ptr(), nsp.data_ptr(), B, 2, H, hip.SMALL_X_F32, st)
         # F5 head transform: dense + GELU, LayerNorm
-        gt = self.buf("h.gt", (T, H))
-        ut = self.buf("h.ut", (T, H))
+        gt = self.buf("h.gt", (cap_rows, H))
+        ut = self.buf("h.ut", (cap_rows, H))
         self.gemm(seq_out, w("cls.predictions.transform.dense.weight"), gt, T, H, H,
                   flags=hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT,
                   bias=f("cls.predictions.transform.dense.bias"), aux=ut)
-        t = self.buf("h.t", (T, H))
-        stt = self.buf("h.stt", (2, T), F32)
+        t = self.buf("h.t", (cap_rows, H))
+        stt = self.buf("h.stt", (2, cap_rows), F32)
         hip.call("stonk_layernorm_fwd", gt.data_ptr(), f("cls.predictions.transform.LayerNorm.weight").data_ptr(),
                  f("cls.predictions.transform.LayerNorm.bias").data_ptr(), t.data_ptr(), stt[0].data_ptr(),
                  stt[1].data_ptr(), T, H, cfg.layer_norm_eps, 0, 0.0, 0, st)
-        out = dict(hidden_states=seq_out.view(B, S, H), pooler_output=pooled, nsp_logits=nsp)
+        out = dict(hidden_states=seq_out.view(B, S, H) if plan is None else None, pooler_output=pooled, nsp_logits=nsp)
         heads = (("text", "cls.predictions.text_decoder.weight", cfg.vocab_size, 0, mlm_labels),
                  ("ent", "cls.predictions.entity_decoder.weight", cfg.kg_vocab_size, half, ent_labels))
-        have_labels = mlm_labels is not None and ent_labels is not None and nsp_labels is not None
         # F6 label-sparse decoders + fused softmax cross-entropy (value and logits-gradient in one sweep)
         if have_labels:
             acc = self.buf("l.acc", (8,), F32)  # [text_sum, ent_sum, nsp_sum, nsp_cnt, loss x4]
@@ -514,7 +586,7 @@ class Engine:
                 tg = self.buf(f"l.{nm}.tg", (cap,), I32)
                 cnt = cnts[hi:hi + 1]
                 hip.call("stonk_label_compact", labels.data_ptr(), cap, half, S, off, rows.data_ptr(), tg.data_ptr(),
-                         cnt.data_ptr(), st)
+                         cnt.data_ptr(), hip.ptr(row_of_pos), st)
                 hs = self.buf(f"l.{nm}.hs", (cap, H))
                 hip.call("stonk_gather_rows_bf16", t.data_ptr(), H, rows.data_ptr(), cnt.data_ptr(), hs.data_ptr(), H, H,
                          cap, st)
@@ -568,14 +640,14 @@ class Engine:
         cfg = self.cfg
         H, S, half = cfg.hidden_size, cfg.max_position_embeddings, cfg.half_length
         B = sv["B"]
-        T = B * S
+        T, cap_rows = sv["T"], B * S
         st = hip.stream_ptr()
         P = self.P
         f, g_, wt = P.view, P.grad_view, P.wt
         cap = B * half
         notify = self._make_notify(on_segment_done)
         # ---- decoders (label-sparse): dHs = dlogits . W ; dW += dlogits^T . Hs
-        dt = self.buf("b.dt", (T, H))
+        dt = self.buf("b.dt", (cap_rows, H))[:T]
         dt.zero_()
         for nm, wname, N in (("ent", "cls.predictions.entity_decoder.weight", cfg.kg_vocab_size),
                              ("text", "cls.predictions.text_decoder.weight", cfg.vocab_size)):
@@ -600,16 +672,16 @@ class Engine:
             self.wgrad(h["dl"], h["hs"], g_(wname, padded=True), None, npad, H, cap, k_dev=h["cnt"], alpha=gscale)
             notify(wname)
         # ---- head transform backward
-        dgt = self.buf("b.dgt", (T, H))
+        dgt = self.buf("b.dgt", (cap_rows, H))
         hip.call("stonk_layernorm_bwd", dt.data_ptr(), sv["gt"].data_ptr(), sv["stt"][0].data_ptr(),
                  sv["stt"][1].data_ptr(), f("cls.predictions.transform.LayerNorm.weight").data_ptr(), dgt.data_ptr(), 0,
                  g_("cls.predictions.transform.LayerNorm.weight").data_ptr(),
                  g_("cls.predictions.transform.LayerNorm.bias").data_ptr(), T, H, 0, 0.0, 0, 0.0, 0, self.ln_ws().data_ptr(), self.ln_ws().numel(), st)
-        dut = self.buf("b.dut", (T, H))
+        dut = self.buf("b.dut", (cap_rows, H))
         hip.call("stonk_gelu_bwd_bf16", dgt.data_ptr(), sv["ut"].data_ptr(), dut.data_ptr(), T * H, st)
         self.wgrad(dut, sv["seq_out"], g_("cls.predictions.transform.dense.weight"),
                    g_("cls.predictions.transform.dense.bias"), H, H, T)
-        dseq = self.buf("b.dseq", (T, H))
+        dseq = self.buf("b.dseq", (cap_rows, H))
         self.gemm(dut, wt["cls.predictions.transform.dense.weight"], dseq, T, H, H, kernel=self._kernel("dgrad_head", True))
         # ---- NSP + pooler (fp32), pooler gradient lands on position 0 of d(sequence_output)
         dnsp = sv["dnsp"]
@@ -651,25 +723,39 @@ class Engine:
         cfg = self.cfg
         H, S = cfg.hidden_size, cfg.max_position_embeddings
         B = sv["B"]
-        T = B * S
+        T, rows, plan = sv["T"], sv["rows"], sv["plan"]
+        cap = B * S
         st = hip.stream_ptr()
         f, g_ = self.P.view, self.P.grad_view
-        hip.call("stonk_small_linear_bwd", dpooled.data_ptr(), sv["pooled"].data_ptr(), sv["seq_out"].data_ptr(), S * H,
-                 f("bert.pooler.dense.weight").data_ptr(), g_("bert.pooler.dense.weight").data_ptr(),
-                 g_("bert.pooler.dense.bias").data_ptr(), 0, dseq.data_ptr(), S * H, B, H, H, hip.SMALL_TANH, st)
+        if plan is None:
+            acc, ld_acc = dseq, S * H
+        else:   # packed: position 0 of sequence b is row cu[b] - its gradient rows are gathered, added to, scattered back
+            nb = self.buf("u.nb", (1,), I32)
+            nb.fill_(B)
+            acc, ld_acc = self.buf("b.dfirst", ((B + 127) // 128 * 128, H)), H
+            hip.call("stonk_gather_rows_bf16", dseq.data_ptr(), H, plan["cu"].data_ptr(), nb.data_ptr(), acc.data_ptr(), H,
+                     H, acc.shape[0], st)
+        hip.call("stonk_small_linear_bwd", dpooled.data_ptr(), sv["pooled"].data_ptr(), sv["first"].data_ptr(),
+                 sv["ld_first"], f("bert.pooler.dense.weight").data_ptr(), g_("bert.pooler.dense.weight").data_ptr(),
+                 g_("bert.pooler.dense.bias").data_ptr(), 0, acc.data_ptr(), ld_acc, B, H, H, hip.SMALL_TANH, st)
+        if plan is not None:
+            hip.call("stonk_scatter_rows_bf16", acc.data_ptr(), H, plan["cu"].data_ptr(), nb.data_ptr(), dseq.data_ptr(), H,
+                     H, st)
         notify("bert.pooler.dense.bias")
         # ---- encoder layers, last to first
         dy = dseq
+        cu = None if plan is None else plan["cu"]
         span = self._span_begin()
         for i in reversed(range(cfg.num_hidden_layers)):
             prefix = f"bert.encoder.layer.{i}"
-            dy = self.layer_bwd(prefix, dy, B, S, sv["attention_mask"], sv["p_hid"], sv["p_att"], i, sv[prefix])
+            dy = self.layer_bwd(prefix, dy, B, S, sv["attention_mask"], sv["p_hid"], sv["p_att"], i, sv[prefix], T=T, cu=cu,
+                                rows=rows)
             notify(prefix)
         if span is not None and self._wstream is not None:   # (timing only) the span ends when the layers' weight gradients have
             torch.cuda.current_stream().wait_stream(self._wstream)
         self._span_end("encoder_bwd", span)
         # ---- embeddings LayerNorm, position / token-type embeddings
-        dsum = self.buf("b.dsum0", (T, H))
+        dsum = self.buf("b.dsum0", (cap, H))
         p_hid = sv["p_hid"]
         hip.call("stonk_layernorm_bwd", dy.data_ptr(), sv["sum0"].data_ptr(), sv["st0"][0].data_ptr(),
                  sv["st0"][1].data_ptr(), f("bert.embeddings.LayerNorm.weight").data_ptr(), dsum.data_ptr(), 0,
@@ -677,7 +763,8 @@ class Engine:
                  hip.LN_DROPOUT if p_hid > 0 else 0, p_hid, self.seed(200, 0), 0.0, 0, self.ln_ws().data_ptr(), self.ln_ws().numel(), st)
         hip.call("stonk_embed_grad", dsum.data_ptr(), hip.ptr(sv["token_type_ids"]),
                  g_("bert.embeddings.position_embeddings.weight").data_ptr(),
-                 g_("bert.embeddings.token_type_embeddings.weight").data_ptr(), B, S, H, cfg.type_vocab_size, st)
+                 g_("bert.embeddings.token_type_embeddings.weight").data_ptr(), B, S, H, cfg.type_vocab_size,
+                 0 if plan is None else plan["row_of_pos"].data_ptr(), st)
         notify("bert.embeddings")
         self.join_wgrad()
 
@@ -691,7 +778,10 @@ class Engine:
         st = hip.stream_ptr()
         f = self.P.view
         save: dict = {}
-        seq_out, pooled = self.encode(input_ids, attention_mask, token_type_ids, training, save)
+        # (the classification head hands out no per-position output: in training the encoder runs on the packed rows)
+        packed = need_backward and labels is not None
+        seq_out, pooled = self.encode(input_ids, attention_mask, token_type_ids, training, save,
+                                      (None, None) if packed else None)
         p = cfg.hidden_dropout_prob if training else 0.0
         dropped = pooled
         if p > 0:
@@ -700,7 +790,8 @@ class Engine:
         logits = self.buf("c.logits", (B, num_labels), F32)
         hip.call("stonk_small_linear_fwd", dropped.data_ptr(), H, f("classifier.weight").data_ptr(),
                  f("classifier.bias").data_ptr(), logits.data_ptr(), B, num_labels, H, hip.SMALL_X_F32, st)
-        out = dict(logits=logits, hidden_states=seq_out.view(B, cfg.max_position_embeddings, H), pooler_output=pooled)
+        out = dict(logits=logits, pooler_output=pooled,
+                   hidden_states=seq_out.view(B, cfg.max_position_embeddings, H) if save["plan"] is None else None)
         if labels is not None:
             acc = self.buf("c.acc", (2,), F32)
             acc.zero_()
@@ -737,5 +828,5 @@ class Engine:
             hip.call("stonk_dropout_f32", dpooled.data_ptr(), dpooled.data_ptr(), B * H, sv["p_cls"], self.seed(300, 0), st)
         notify("classifier.bias")
         dseq = self.buf("b.dseq", (B * S, H))
-        dseq.zero_()  # only position 0 of every sequence receives a gradient (from the pooler)
+        dseq[:sv["T"]].zero_()  # only position 0 of every sequence receives a gradient (from the pooler)
         self.backward_encoder(dpooled, dseq, sv, notify)

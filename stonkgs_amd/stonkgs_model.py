@@ -417,8 +417,10 @@ class STonKGsForPreTraining(nn.Module):
         self._sync_derived()
         need_bwd = have_labels and torch.is_grad_enabled() and training
         dense = self.materialize_logits if self.materialize_logits is not None else not training
+        # (hidden states leave only in the dataclass: a tuple-returning training forward may run the encoder unpadded)
         out = self.engine.forward(input_ids, attention_mask, token_type_ids, mlm if have_labels else None,
-                                  elm if have_labels else None, nsp if have_labels else None, training, dense, need_bwd)
+                                  elm if have_labels else None, nsp if have_labels else None, training, dense, need_bwd,
+                                  want_hidden=bool(return_dict) or not need_bwd)
         total_loss = None
         if have_labels:
             total_loss = out["loss"]
@@ -472,7 +474,7 @@ class STonKGsForPreTraining(nn.Module):
         self._sync_derived()
         out = self.engine.forward(t["input_ids"], t.get("attention_mask"), t.get("token_type_ids"),
                                   t["masked_lm_labels"], t["ent_masked_lm_labels"], t["next_sentence_labels"],
-                                  self.training, False, True)
+                                  self.training, False, True, want_hidden=False)
         loss = out["loss"].clone()
         self.last_loss_terms = tuple(out[k].clone() for k in _TERM_KEYS)
         self.engine.backward(gscale, on_segment_done)

@@ -103,3 +103,41 @@ def test_device_batcher_feeds_a_training_step_and_reports_bad_nodes(hip):
         bat.check_errors()
     with pytest.raises(ValueError):
         bat(text[:, :100], att[:, :100], src, tgt, 0)
+
+
+@pytest.mark.parametrize("B,S", [(64, 512), (5, 256), (1, 512), (300, 128)])
+def test_unpad_plan_equals_numpy_restatement(hip, B, S):
+    """Row plan of the unpadded encoder (csrc/unpad.hip) against oracle/masking_oracle.unpad_plan - integer work, equality:
+    prefix masks of every length, holes inside the text half, labelled padding positions, a sequence without any live key
+    (keeps everything), one that is all live, masked positions inside the ENTITY half with and without labels."""
+    half = S // 2
+    rng = np.random.RandomState(B + S)
+    am = np.ones((B, S), dtype=np.int64)
+    n_text = rng.randint(1, half + 1, B)
+    for b in range(B):
+        am[b, n_text[b]:half] = 0
+    if B > 2:
+        am[1, :] = 0                       # no live key at all
+        am[2, 3:9] = 0                     # a hole in the text half
+        am[2, half + 5:half + 40] = 0      # masked entity positions
+    tl = np.full((B, half), -100, dtype=np.int64)
+    el = np.full((B, half), -100, dtype=np.int64)
+    for lab in (tl, el):
+        pick = rng.rand(B, half) < 0.15
+        lab[pick] = rng.randint(0, 1000, int(pick.sum()))
+    dev = lambda a: torch.from_numpy(a).cuda()
+    d_am, d_tl, d_el = dev(am), dev(tl), dev(el)
+    for use_labels in (True, False):
+        rop = torch.full((B * S,), -7, dtype=torch.int32, device="cuda")
+        por = torch.full((B * S,), -7, dtype=torch.int32, device="cuda")
+        cu = torch.full((B + 1,), -7, dtype=torch.int32, device="cuda")
+        rm = torch.full((B * S,), -7, dtype=torch.int64, device="cuda")
+        ws = torch.zeros(int(hip.lib().stonk_unpad_workspace_ints(B)), dtype=torch.int32, device="cuda")
+        hip.call("stonk_unpad_plan", hip.ptr(d_am), hip.ptr(d_tl) if use_labels else 0, hip.ptr(d_el) if use_labels else 0,
+                 B, S, half, hip.ptr(rop), hip.ptr(por), hip.ptr(cu), hip.ptr(rm), hip.ptr(ws), ws.numel(), hip.stream_ptr())
+        e_rop, e_por, e_cu, e_rm = mo.unpad_plan(am, tl if use_labels else None, el if use_labels else None)
+        assert np.array_equal(cu.cpu().numpy(), e_cu)
+        assert np.array_equal(rop.cpu().numpy(), e_rop) and np.array_equal(por.cpu().numpy(), e_por)
+        assert np.array_equal(rm.cpu().numpy(), e_rm)
+        total = int(e_cu[-1])
+        assert 0 < total <= B * S and (use_labels is False or total >= int((am != 0).sum()))

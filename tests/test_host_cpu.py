@@ -286,3 +286,29 @@ def test_embedding_row_builder_matches_the_reference():
     assert df["input_ids"].tolist() == gold["input_ids"].tolist() and list(df.columns)[:3] == ["input_ids", "attention_mask", "token_type_ids"]
     with pytest.raises(FileNotFoundError):
         next(preprocess_df_for_embeddings_iter(rows, nlp_model_type="dmis-lab/biobert-v1.1", **kw))
+
+
+def test_unpad_plan_restatement_keeps_exactly_what_the_loss_reads():
+    """oracle/masking_oracle.unpad_plan (the checker of csrc/unpad.hip): live keys, labelled positions and position 0 are
+    kept in position order, nothing else; a sequence without live keys keeps everything; the maps invert each other."""
+    import numpy as np
+
+    from oracle import masking_oracle as mo
+
+    B, S = 4, 16
+    half = S // 2
+    am = np.ones((B, S), dtype=np.int64)
+    am[0, 3:half] = 0
+    am[1, :] = 0
+    am[2, 0] = 0                    # position 0 masked: still kept (the pooler reads it)
+    tl = np.full((B, half), -100)
+    el = np.full((B, half), -100)
+    tl[0, 5] = 17                   # a labelled padding position
+    rop, por, cu, rm = mo.unpad_plan(am, tl, el)
+    kept0 = [0, 1, 2, 5] + list(range(half, S))
+    assert cu.tolist() == [0, len(kept0), len(kept0) + S, len(kept0) + 2 * S, len(kept0) + 3 * S]
+    assert por[:len(kept0)].tolist() == kept0 and rop[3] == -1 and rop[5] == 3
+    assert rm[:len(kept0)].tolist() == [1, 1, 1, 0] + [1] * half            # the labelled pad row is a query, never a key
+    total = int(cu[-1])
+    assert (rop[por[:total]] == np.arange(total)).all() and (por[total:] == -1).all()
+    assert rm[cu[2]] == 0 and rop[2 * S] == cu[2]

@@ -83,7 +83,7 @@ def test_label_compact_gather_scatter(hip):
     rows = torch.full((n,), -1, device="cuda", dtype=torch.int32)
     tg = torch.full((n,), -1, device="cuda", dtype=torch.int32)
     cnt = torch.zeros(1, device="cuda", dtype=torch.int32)
-    hip.call("stonk_label_compact", hip.ptr(labels), n, half, S, half, hip.ptr(rows), hip.ptr(tg), hip.ptr(cnt),
+    hip.call("stonk_label_compact", hip.ptr(labels), n, half, S, half, hip.ptr(rows), hip.ptr(tg), hip.ptr(cnt), 0,
              hip.stream_ptr())
     idx = (labels.view(-1) != -100).nonzero().squeeze(1)
     c = cnt.item()

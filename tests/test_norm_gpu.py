@@ -110,7 +110,7 @@ def test_joint_embed_ln(hip):
     err = torch.zeros(1, device="cuda", dtype=torch.int32)
     hip.call("stonk_joint_embed_ln_fwd", hip.ptr(ids), hip.ptr(tt), hip.ptr(text_h), hip.ptr(table), hip.ptr(pos),
              hip.ptr(typ), hip.ptr(gamma), hip.ptr(beta), hip.ptr(ssum), hip.ptr(y), hip.ptr(mean), hip.ptr(rstd),
-             B, S, half, H, KG + 3, 2, 1e-12, 0, 0.0, 0, hip.ptr(err), hip.stream_ptr())
+             B, S, half, H, KG + 3, 2, 1e-12, 0, 0.0, 0, hip.ptr(err), 0, 0, hip.stream_ptr())
     emb = torch.cat([text_h.float().view(B, half, H), table[ids[:, half:]]], 1) + pos[None] + typ[tt]
     torch.testing.assert_close(ssum.float().view(B, S, H), emb, rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(y.float().view(B, S, H), F.layer_norm(emb, (H,), gamma, beta, 1e-12), rtol=1e-2, atol=1e-2)
@@ -118,7 +118,7 @@ def test_joint_embed_ln(hip):
     ids[1, half + 2] = KG + 3  # out-of-table entity id: the reference raises KeyError; the kernel raises the flag
     hip.call("stonk_joint_embed_ln_fwd", hip.ptr(ids), hip.ptr(tt), hip.ptr(text_h), hip.ptr(table), hip.ptr(pos),
              hip.ptr(typ), hip.ptr(gamma), hip.ptr(beta), hip.ptr(ssum), hip.ptr(y), hip.ptr(mean), hip.ptr(rstd),
-             B, S, half, H, KG + 3, 2, 1e-12, 0, 0.0, 0, hip.ptr(err), hip.stream_ptr())
+             B, S, half, H, KG + 3, 2, 1e-12, 0, 0.0, 0, hip.ptr(err), 0, 0, hip.stream_ptr())
     assert err.item() & 1
 
 
@@ -141,7 +141,7 @@ def test_text_embed_ln_and_embed_grad(hip):
     tt = torch.randint(0, 2, (B, S), device="cuda")
     dpos = torch.zeros(S, H, device="cuda")
     dtyp = torch.zeros(2, H, device="cuda")
-    hip.call("stonk_embed_grad", hip.ptr(dx), hip.ptr(tt), hip.ptr(dpos), hip.ptr(dtyp), B, S, H, 2, hip.stream_ptr())
+    hip.call("stonk_embed_grad", hip.ptr(dx), hip.ptr(tt), hip.ptr(dpos), hip.ptr(dtyp), B, S, H, 2, 0, hip.stream_ptr())
     d = dx.float().view(B, S, H)
     torch.testing.assert_close(dpos, d.sum(0), rtol=1e-4, atol=1e-4)
     for t in (0, 1):

@@ -207,6 +207,12 @@ int stonk_small_linear_bwd(const float* dy, const float* y, const void* x, int64
  * vector (replayable from the seed), and *out = *num / *den for the mean of a device-side loss sum. */
 int stonk_dropout_f32(const float* x, float* y, int64_t n, float p, uint32_t seed, void* stream);
 int stonk_ratio_f32(const float* num, const float* den, float* out, void* stream);
+/* The classification head's other two losses (ref:stonkgs_finetuning.py:328-338): `mode` = STONK_LOSS_MSE (regression,
+ * nn.MSELoss), STONK_LOSS_MSE_BROADCAST (num_labels = 1 with 1-D labels: torch broadcasts [B,1] against [B] to [B,B], and
+ * so does this), STONK_LOSS_BCE (multi-label, nn.BCEWithLogitsLoss). logits / targets fp32 [B,C] ([B] targets for the
+ * broadcast mode); *loss_out = the mean; dlogits (nullable) = d(loss * grad_scale)/d(logits). */
+int stonk_elementwise_loss_fwd_bwd(const float* logits, const float* targets, int B, int C, int mode, float* loss_out,
+                                   float* dlogits, float grad_scale, void* stream);
 
 /* du = dg * gelu'(u), bf16 elementwise (backward of hf:modeling_bert.py:478, the head transform's activation). */
 int stonk_gelu_bwd_bf16(const void* dg, const void* u, void* du, int64_t n, void* stream);

@@ -203,8 +203,11 @@ def model_case(name, sm, pre, cfg: orc.OracleConfig, B, seed, full_logits):
     print(name, "loss", float(out.loss), "grad_norm", float(total_norm), "dead", len(dead))
 
 
-def classification_case(name, sm, ft, pre, cfg: orc.OracleConfig, B, seed, num_labels):
-    """G6: STonKGsForSequenceClassification (config 5) - the reference's fine-tuning forward, loss and gradients."""
+def classification_case(name, sm, ft, pre, cfg: orc.OracleConfig, B, seed, num_labels, problem=None):
+    """G6: STonKGsForSequenceClassification (config 5) - the reference's fine-tuning forward, loss and gradients.
+    `problem`: None = integer class labels (the reference infers single_label_classification, :318-326);
+    "regression_1d" = num_labels 1 with float labels of shape [B] (MSELoss broadcasts [B,1] x [B] to [B,B]: the
+    reference's own behaviour), "regression" = float labels [B, num_labels], "multi_label" = 0/1 float labels [B, num_labels]."""
     from transformers import BertConfig, BertForPreTraining, BertModel
 
     sd = orc.init_state_dict(cfg, seed=seed)
@@ -220,6 +223,8 @@ def classification_case(name, sm, ft, pre, cfg: orc.OracleConfig, B, seed, num_l
                         hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, attn_implementation="eager",
                         num_labels=num_labels)
     hf_cfg.update({"kg_vocab_size": cfg.kg_vocab_size})
+    if problem == "regression":   # (num_labels > 1 with float labels is inferred as multi-label: regression must be set)
+        hf_cfg.problem_type = "regression"
 
     class RefCls(ft.STonKGsForSequenceClassification):  # forward is the reference's; only the hub-fetching init is not
         def __init__(self, c):
@@ -247,9 +252,22 @@ def classification_case(name, sm, ft, pre, cfg: orc.OracleConfig, B, seed, num_l
             model.kg_backbone[sid] = model.lm_backbone(torch.tensor([[sid]]))[0][0][0]
     batch = make_batch(cfg, B, seed + 2, pre)
     rng = np.random.RandomState(seed + 4)
-    labels = torch.tensor(rng.randint(0, num_labels, B))
-    out = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
-                token_type_ids=batch["token_type_ids"], labels=labels, return_dict=True)
+    if problem is None:
+        labels = torch.tensor(rng.randint(0, num_labels, B))
+    elif problem == "regression_1d":
+        labels = torch.tensor(rng.randn(B).astype(np.float32))
+    elif problem == "regression":
+        labels = torch.tensor(rng.randn(B, num_labels).astype(np.float32))
+    else:
+        labels = torch.tensor(rng.randint(0, 2, (B, num_labels)).astype(np.float32))
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
+                    token_type_ids=batch["token_type_ids"], labels=labels, return_dict=True)
+    assert problem is None or model.config.problem_type == ("multi_label_classification" if problem == "multi_label"
+                                                            else "regression")
     model.zero_grad()
     out.loss.backward()
     params = dict(model.named_parameters())
@@ -266,7 +284,7 @@ def classification_case(name, sm, ft, pre, cfg: orc.OracleConfig, B, seed, num_l
                                                     "num_attention_heads", "intermediate_size",
                                                     "max_position_embeddings", "type_vocab_size", "layer_norm_eps")},
             "B": B, "weight_seed": seed, "table_seed": seed + 1, "batch_seed": seed + 2, "classifier_seed": seed + 3,
-            "num_labels": num_labels, "table_std": 0.3,
+            "num_labels": num_labels, "table_std": 0.3, "problem": problem, "problem_type": model.config.problem_type,
             "weights_checksum": float(sum(v.double().abs().sum() for k, v in sd.items() if not k.startswith("classifier"))),
             "table_checksum": float(tsv_rows.abs().sum()), "grad_keys": keys, "torch": torch.__version__}
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
@@ -624,6 +642,14 @@ def main():
                        orc.OracleConfig(vocab_size=512, kg_vocab_size=300, hidden_size=128, num_hidden_layers=2,
                                         num_attention_heads=2, intermediate_size=256, max_position_embeddings=256),
                        B=4, seed=800, steps=200, lr=1e-3, n_batches=6)
+        return
+    if only == "cls_losses":   # round 3: the regression / multi-label branches of the fine-tuning head
+        ft = import_reference_finetuning()
+        small = orc.OracleConfig(vocab_size=512, kg_vocab_size=300, hidden_size=128, num_hidden_layers=2,
+                                 num_attention_heads=2, intermediate_size=256, max_position_embeddings=256)
+        classification_case("g13_cls_regression_1d", sm, ft, pre, small, B=5, seed=310, num_labels=1, problem="regression_1d")
+        classification_case("g14_cls_regression", sm, ft, pre, small, B=4, seed=320, num_labels=3, problem="regression")
+        classification_case("g15_cls_multilabel", sm, ft, pre, small, B=6, seed=330, num_labels=3, problem="multi_label")
         return
     if only in ("shape", "f3"):   # (re)generate only the round-2 cases
         if only == "shape":

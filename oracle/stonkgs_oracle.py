@@ -203,14 +203,25 @@ def encode(sd, cfg: OracleConfig, kg_table: Tensor, input_ids, attention_mask=No
 
 
 def forward_classification(sd, cfg: OracleConfig, kg_table: Tensor, input_ids, attention_mask=None, token_type_ids=None,
-                           labels=None) -> Dict[str, Tensor]:
-    """STonKGsForSequenceClassification.forward, single-label path (ref:src/stonkgs/models/stonkgs_finetuning.py:259-346):
-    same embedding front and encoder, pooled -> dropout (p = 0 here) -> classifier -> CrossEntropyLoss."""
+                           labels=None, problem_type: str = "single_label_classification") -> Dict[str, Tensor]:
+    """STonKGsForSequenceClassification.forward (ref:src/stonkgs/models/stonkgs_finetuning.py:259-346): same embedding
+    front and encoder, pooled -> dropout (p = 0 here) -> classifier -> the loss of `problem_type` (:328-338):
+    CrossEntropyLoss / MSELoss on logits.view(-1, num_labels) (torch's own broadcasting included) / BCEWithLogitsLoss."""
     seq, pooled = encode(sd, cfg, kg_table, input_ids, attention_mask, token_type_ids)
     logits = _linear(pooled, sd, "classifier")
     out = {"logits": logits, "pooler_output": pooled, "hidden_states": seq}
     if labels is not None:
-        out["loss"] = F.cross_entropy(logits.view(-1, logits.shape[-1]), labels.view(-1))
+        nl = logits.shape[-1]
+        if problem_type == "regression":
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")   # ([B,1] against [B]: broadcast to [B,B], as in the reference)
+                out["loss"] = F.mse_loss(logits.view(-1, nl), labels)
+        elif problem_type == "multi_label_classification":
+            out["loss"] = F.binary_cross_entropy_with_logits(logits, labels)
+        else:
+            out["loss"] = F.cross_entropy(logits.view(-1, nl), labels.view(-1))
     return out
 
 

@@ -28,6 +28,7 @@ GEMM_AUTO, GEMM_TILE128, GEMM_WAVE8, GEMM_WAVE4, GEMM_WAVE4_192, GEMM_DISPATCHED
 LN_DROPOUT = 1 << 0
 SMALL_TANH = 1
 SMALL_X_F32 = 16
+LOSS_MSE, LOSS_MSE_BROADCAST, LOSS_BCE = 0, 1, 2
 
 _vp, _i32, _i64, _f32, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 
@@ -67,6 +68,7 @@ _SIGNATURES = {
     "stonk_small_linear_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "stonk_dropout_f32": [_vp, _vp, _i64, _f32, _u32, _vp],
     "stonk_ratio_f32": [_vp, _vp, _vp, _vp],
+    "stonk_elementwise_loss_fwd_bwd": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _f32, _vp],
     "stonk_gelu_bwd_bf16": [_vp, _vp, _vp, _i64, _vp],
     "stonk_sumsq_f32": [_vp, _i64, _vp, _vp, _i64, _vp],
     "stonk_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _f32, _f32,

@@ -162,7 +162,77 @@ __global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restric
     y[i] = stonk_keep(0u, (uint32_t)i, seed, thr32) ? x[i] * scale : 0.f;
 }
 __global__ void ratio_kernel(const float* num, const float* den, float* out) { *out = *num / *den; }
+// Classification-head losses other than cross-entropy (ref:src/stonkgs/models/stonkgs_finetuning.py:328-338), mean over
+// all B x C elements, one workgroup (B is a batch, C a handful of labels):
+//   STONK_LOSS_MSE            torch.nn.MSELoss()(logits [B,C], targets [B,C])
+//   STONK_LOSS_MSE_BROADCAST  the same call with C = 1 and targets of shape [B]: torch broadcasts [B,1] against [B] to
+//                             [B,B] (with a warning) - what the reference computes for num_labels = 1 and 1-D labels:
+//                             mean_ij (x_i - y_j)^2, d/dx_i = 2 (x_i - mean(y)) / B
+//   STONK_LOSS_BCE            torch.nn.BCEWithLogitsLoss()(logits, targets): max(x,0) - x y + log(1 + exp(-|x|))
+__global__ __launch_bounds__(256) void elementwise_loss_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                               int B, int C, int mode, float* __restrict__ loss_out,
+                                                               float* __restrict__ dx, float gscale) {
+  __shared__ float red[4];
+  __shared__ float s_mean_y, s_mean_y2;
+  const int n = B * C;
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  if (mode == STONK_LOSS_MSE_BROADCAST) {
+    float sy = 0.f, sy2 = 0.f;
+    for (int j = threadIdx.x; j < B; j += 256) {
+      sy += y[j];
+      sy2 += y[j] * y[j];
+    }
+    sy = block_sum(sy);
+    sy2 = block_sum(sy2);
+    if (threadIdx.x == 0) {
+      s_mean_y = sy / (float)B;
+      s_mean_y2 = sy2 / (float)B;
+    }
+    __syncthreads();
+  }
+  float local = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float xi = x[i];
+    float l, g;
+    if (mode == STONK_LOSS_MSE) {
+      const float d = xi - y[i];
+      l = d * d;
+      g = 2.f * d;
+    } else if (mode == STONK_LOSS_MSE_BROADCAST) {
+      l = xi * xi - 2.f * xi * s_mean_y + s_mean_y2;   // mean_j (x_i - y_j)^2
+      g = 2.f * (xi - s_mean_y);
+    } else {
+      const float yi = y[i];
+      const float e = __expf(-fabsf(xi));
+      l = fmaxf(xi, 0.f) - xi * yi + log1pf(e);
+      const float sig = xi >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+      g = sig - yi;
+    }
+    local += l;
+    if (dx) dx[i] = g * gscale / (float)n;
+  }
+  local = block_sum(local);
+  if (threadIdx.x == 0) *loss_out = local / (float)n;
+}
+
 }  // namespace
+
+extern "C" int stonk_elementwise_loss_fwd_bwd(const float* logits, const float* targets, int B, int C, int mode,
+                                              float* loss_out, float* dlogits, float grad_scale, void* stream) {
+  STONK_CHECK_ARG(logits && targets && loss_out, STONK_EINVAL);
+  STONK_CHECK_ARG(B > 0 && C > 0 && (long)B * C < (1L << 24), STONK_ESHAPE);
+  STONK_CHECK_ARG(mode == STONK_LOSS_MSE || mode == STONK_LOSS_BCE || (mode == STONK_LOSS_MSE_BROADCAST && C == 1),
+                  STONK_EINVAL);
+  hipLaunchKernelGGL(elementwise_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, targets, B, C, mode,
+                     loss_out, dlogits, grad_scale);
+  return stonk_launch_status();
+}
 
 extern "C" int stonk_dropout_f32(const float* x, float* y, int64_t n, float p, uint32_t seed, void* stream) {
   STONK_CHECK_ARG(x && y && n >= 0 && p >= 0.f && p < 1.f, STONK_EINVAL);

@@ -35,3 +35,7 @@
 // --- stonk_small_linear_* `act` ---
 #define STONK_SMALL_TANH 1
 #define STONK_SMALL_X_F32 16 /* x is fp32 (default bf16) */
+// --- stonk_elementwise_loss_fwd_bwd `mode` (ref:src/stonkgs/models/stonkgs_finetuning.py:328-338) ---
+#define STONK_LOSS_MSE 0            /* regression: MSELoss over [B,C] */
+#define STONK_LOSS_MSE_BROADCAST 1  /* regression with num_labels = 1 and 1-D labels: torch's [B,1] x [B] -> [B,B] broadcast */
+#define STONK_LOSS_BCE 2            /* multi-label: BCEWithLogitsLoss over [B,C] */

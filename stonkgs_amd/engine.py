@@ -102,7 +102,9 @@ class Engine:
         # nor dense logits (`forward_backward`, `forward(..., return_dict=False)` in training mode); costs one host wait
         # per step for the packed row count, taken while the frozen backbone's forward is already queued.
         self.unpad = True
-        self.rows_executed = [0, 0, 0]   # packed rows run, padded rows they stand for, steps (bench: executed FLOPs)
+        # what ran: [rows, padded rows they stand for, encoder passes, sum over sequences of rows^2, of S^2] - bench.py prices
+        # the step on the FLOPs actually executed (linear layers ~ rows, attention ~ rows^2 per sequence)
+        self.rows_executed = [0, 0, 0, 0, 0]
         self._plan_host: Optional[torch.Tensor] = None
         self._wstream: Optional[torch.cuda.Stream] = None
         # The optimizer (grad-norm, AdamW, W^T refresh: ~2 ms of HBM-bound work) runs on a third stream; the next step's
@@ -466,9 +468,9 @@ class Engine:
         hip.call("stonk_unpad_plan", attention_mask.data_ptr(), hip.ptr(mlm_labels), hip.ptr(ent_labels), B, S, half,
                  row_of_pos.data_ptr(), pos_of_row.data_ptr(), cu.data_ptr(), row_mask.data_ptr(), ws.data_ptr(),
                  ws.numel(), hip.stream_ptr())
-        if self._plan_host is None:
-            self._plan_host = torch.empty(1, dtype=I32).pin_memory()
-        self._plan_host.copy_(cu[B:B + 1], non_blocking=True)
+        if self._plan_host is None or self._plan_host.numel() < B + 1:
+            self._plan_host = torch.empty(B + 1, dtype=I32).pin_memory()
+        self._plan_host[:B + 1].copy_(cu, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         return dict(row_of_pos=row_of_pos, pos_of_row=pos_of_row, cu=cu, row_mask=row_mask), ev
@@ -497,12 +499,15 @@ class Engine:
         T, rows, cu, mask = cap, cap, None, attention_mask
         if plan is not None:
             ev.synchronize()                       # (the backbone's launches are queued: the GPU is not waiting for us)
-            rows = int(self._plan_host[0])
+            offs = self._plan_host[:B + 1].tolist()
+            rows = offs[B]
             T = min(cap, (rows + 63) // 64 * 64)   # whole 64-row K tiles for the weight gradients; the tail rows are zeros
             cu, mask = plan["cu"], plan["row_mask"]
-        self.rows_executed[0] += T
-        self.rows_executed[1] += cap
-        self.rows_executed[2] += 1
+            sq = sum((offs[i + 1] - offs[i]) ** 2 for i in range(B))
+        else:
+            sq = B * S * S
+        for i, v in enumerate((T, cap, 1, sq, B * S * S)):
+            self.rows_executed[i] += v
         # F2 gather + concat + embeddings LayerNorm
         sum0 = self.buf("e.sum0", (cap, H))
         x = self.buf("e.x0", (cap, H))
@@ -770,8 +775,10 @@ class Engine:
 
     # ------------------------------------------------------------------ sequence classification head (config 5)
     def forward_cls(self, input_ids, attention_mask, token_type_ids, labels, num_labels: int, training: bool,
-                    need_backward: bool):
-        """pooled -> dropout -> Linear(H, num_labels) -> CrossEntropyLoss (ref:stonkgs_finetuning.py:310-330)."""
+                    need_backward: bool, loss_mode: Optional[int] = None):
+        """pooled -> dropout -> Linear(H, num_labels) -> loss (ref:stonkgs_finetuning.py:310-338). `loss_mode` None:
+        CrossEntropyLoss on int64 labels [B]; hip.LOSS_MSE / LOSS_MSE_BROADCAST / LOSS_BCE: the regression and
+        multi-label branches on fp32 labels."""
         cfg = self.cfg
         H = cfg.hidden_size
         B = input_ids.shape[0]
@@ -793,13 +800,17 @@ class Engine:
         out = dict(logits=logits, pooler_output=pooled,
                    hidden_states=seq_out.view(B, cfg.max_position_embeddings, H) if save["plan"] is None else None)
         if labels is not None:
-            acc = self.buf("c.acc", (2,), F32)
-            acc.zero_()
             dl = self.buf("c.dl", (B, num_labels), F32) if need_backward else None
-            hip.call("stonk_nsp_xent_fwd_bwd", logits.data_ptr(), labels.data_ptr(), B, num_labels, acc.data_ptr(),
-                     hip.ptr(dl), 1.0, self.err.data_ptr(), st)
             loss = self.buf("c.loss", (1,), F32)
-            hip.call("stonk_ratio_f32", acc[0:1].data_ptr(), acc[1:2].data_ptr(), loss.data_ptr(), st)
+            if loss_mode is None:
+                acc = self.buf("c.acc", (2,), F32)
+                acc.zero_()
+                hip.call("stonk_nsp_xent_fwd_bwd", logits.data_ptr(), labels.data_ptr(), B, num_labels, acc.data_ptr(),
+                         hip.ptr(dl), 1.0, self.err.data_ptr(), st)
+                hip.call("stonk_ratio_f32", acc[0:1].data_ptr(), acc[1:2].data_ptr(), loss.data_ptr(), st)
+            else:
+                hip.call("stonk_elementwise_loss_fwd_bwd", logits.data_ptr(), labels.data_ptr(), B, num_labels, loss_mode,
+                         loss.data_ptr(), hip.ptr(dl), 1.0, st)
             out["loss"] = loss[0]
             if need_backward:
                 save.update(dl=dl, dropped=dropped, p_cls=p, num_labels=num_labels)

@@ -516,8 +516,8 @@ class STonKGsForSequenceClassification(STonKGsForPreTraining):
     """Fine-tuning model of BASELINE config 5 (relation-type etc. classification): mirror of
     ref:src/stonkgs/models/stonkgs_finetuning.py:237-346. Same frozen LM backbone + KG table front, same encoder,
     pooled [CLS] -> dropout -> Linear(hidden, num_labels) -> CrossEntropyLoss. Like the reference it inherits from the
-    pre-training class (its MLM/ELM heads stay in the state dict, unused). Only `single_label_classification` is
-    implemented on the HIP path; the regression / multi-label branches of the reference raise NotImplementedError."""
+    pre-training class (its MLM/ELM heads stay in the state dict, unused). The three loss branches of the reference
+    (:328-338) run on the HIP path: CrossEntropyLoss, MSELoss (regression) and BCEWithLogitsLoss (multi-label)."""
 
     _TRAIN_PRETRAINING_HEADS = False
 
@@ -545,12 +545,17 @@ class STonKGsForSequenceClassification(STonKGsForPreTraining):
             t = t.to(device=self._device, dtype=torch.long).contiguous()
         return t
 
-    def _check_problem_type(self, labels):
+    def _labels_and_mode(self, labels):
+        """ref:stonkgs_finetuning.py:316-338: infer `problem_type` once from num_labels and the label dtype, as the
+        reference does, and bring the labels to what the loss kernels read. Returns (labels on the device, loss mode):
+        None = CrossEntropyLoss on int64 [B]; hip.LOSS_MSE / LOSS_MSE_BROADCAST (regression: MSELoss on
+        logits.view(-1, num_labels) - with num_labels = 1 and 1-D labels torch broadcasts [B,1] x [B] to [B,B], and the
+        reference inherits that) / hip.LOSS_BCE (multi-label: BCEWithLogitsLoss) on fp32 labels."""
         if labels is None:
-            return
+            return None, None
+        lt = torch.as_tensor(labels)
         pt = self.config.problem_type
-        if pt is None:  # ref:stonkgs_finetuning.py:318-326
-            lt = torch.as_tensor(labels)
+        if pt is None:
             if self.num_labels == 1:
                 pt = "regression"
             elif self.num_labels > 1 and lt.dtype in (torch.long, torch.int):
@@ -558,19 +563,29 @@ class STonKGsForSequenceClassification(STonKGsForPreTraining):
             else:
                 pt = "multi_label_classification"
             self.config.problem_type = pt
-        if pt != "single_label_classification":
-            raise NotImplementedError(f"problem_type {pt!r}: only single_label_classification runs on the HIP path")
+        if pt == "single_label_classification":
+            return self._prep(lt.reshape(-1)), None
+        if pt not in ("regression", "multi_label_classification"):
+            raise ValueError(f"unknown problem_type {pt!r}")
+        f = lt.to(device=self._device, dtype=torch.float32).contiguous()
+        n, C = f.numel(), self.num_labels
+        if pt == "regression" and C == 1 and f.dim() == 1 and n > 1:
+            return f, hip.LOSS_MSE_BROADCAST
+        B = n // max(C, 1)
+        if n != B * C or (f.dim() > 1 and f.shape[-1] != C):
+            raise ValueError(f"labels of shape {tuple(f.shape)} do not match logits [B, {C}]")
+        return f.view(B, C), hip.LOSS_MSE if pt == "regression" else hip.LOSS_BCE
 
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
                 inputs_embeds=None, labels=None, output_attentions=None, output_hidden_states=None, return_dict=None):
         if input_ids is None:
             raise ValueError("input_ids is required")
-        self._check_problem_type(labels)
-        ids, am, tt, lab = self._prep(input_ids), self._prep(attention_mask), self._prep(token_type_ids), self._prep(labels)
+        lab, mode = self._labels_and_mode(labels)
+        ids, am, tt = self._prep(input_ids), self._prep(attention_mask), self._prep(token_type_ids)
         training = self.training
         self._sync_derived()
         need_bwd = lab is not None and torch.is_grad_enabled() and training
-        out = self.engine.forward_cls(ids, am, tt, lab, self.num_labels, training, need_bwd)
+        out = self.engine.forward_cls(ids, am, tt, lab, self.num_labels, training, need_bwd, mode)
         loss = None
         if lab is not None:
             loss = _ClsStepFunction.apply(self._anchor, self, out["loss"]) if need_bwd else out["loss"].clone()
@@ -580,12 +595,11 @@ class STonKGsForSequenceClassification(STonKGsForPreTraining):
         return SequenceClassifierOutput(loss=loss, logits=logits, hidden_states=None, attentions=None)
 
     def forward_backward(self, inputs, gscale: float = 1.0, on_segment_done=None):
-        labels = inputs.get("labels")
-        self._check_problem_type(labels)
+        lab, mode = self._labels_and_mode(inputs.get("labels"))
         self._sync_derived()
         out = self.engine.forward_cls(self._prep(inputs["input_ids"]), self._prep(inputs.get("attention_mask")),
-                                      self._prep(inputs.get("token_type_ids")), self._prep(labels), self.num_labels,
-                                      self.training, True)
+                                      self._prep(inputs.get("token_type_ids")), lab, self.num_labels,
+                                      self.training, True, mode)
         loss = out["loss"].clone()
         self.engine.backward_cls(gscale, on_segment_done)
         return loss

@@ -21,10 +21,10 @@ def _rel(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-def _g6():
-    with open(os.path.join(GOLDEN, "g6_classification.json")) as f:
+def _g6(name="g6_classification"):
+    with open(os.path.join(GOLDEN, name + ".json")) as f:
         meta = json.load(f)
-    gold = dict(np.load(os.path.join(GOLDEN, "g6_classification.npz")))
+    gold = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     cfg = orc.OracleConfig(**meta["config"])
     sd = orc.init_state_dict(cfg, seed=meta["weight_seed"])
     gw = torch.Generator().manual_seed(meta["classifier_seed"])
@@ -73,6 +73,38 @@ def test_classification_matches_reference_golden(hip):
     # the inherited pre-training heads are present in the checkpoint but frozen and outside the gradient buffer
     assert "cls.predictions.entity_decoder.weight" in model.state_dict()
     assert not params["cls.predictions.entity_decoder.weight"].requires_grad
+    model.engine.check_errors()
+
+
+@pytest.mark.parametrize("name", ["g13_cls_regression_1d", "g14_cls_regression", "g15_cls_multilabel"])
+def test_regression_and_multilabel_heads_match_reference_golden(hip, name):
+    """The other two loss branches of ref:src/stonkgs/models/stonkgs_finetuning.py:328-338 against reference-made goldens:
+    MSELoss (num_labels = 1 with 1-D labels - torch broadcasts [B,1] x [B] to [B,B] and the reference inherits it - and
+    [B,3] with problem_type set) and BCEWithLogitsLoss (inferred from float labels, as the reference infers it)."""
+    cfg, sd, rows, gold, meta = _g6(name)
+    model = _build_cls(cfg, sd, rows, meta["num_labels"])
+    if meta["problem"] == "regression":
+        model.config.problem_type = "regression"       # (the golden set it too: float labels with num_labels > 1 infer multi-label)
+    batch = {k: torch.from_numpy(gold[k]) for k in ("input_ids", "attention_mask", "token_type_ids", "labels")}
+    model.eval()
+    with torch.no_grad():
+        out = model(**batch, return_dict=True)
+    assert model.config.problem_type == meta["problem_type"]
+    assert abs(float(out.loss) - float(gold["loss"])) < 5e-3, (float(out.loss), float(gold["loss"]))
+    assert _rel(out.logits, gold["logits"]) < 3e-2
+    model.train()
+    model._store.grad.zero_()
+    loss, logits = model(**batch)
+    loss.backward()
+    params = dict(model.named_parameters())
+    total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.requires_grad))
+    assert abs(float(total) - float(gold["grad_norm"])) < 4e-2 * float(gold["grad_norm"])
+    for k in meta["grad_keys"]:
+        assert _rel(params[k].grad, gold["grad::" + k]) < 8e-2, k
+    # the fused step takes the same branch
+    model._store.grad.zero_()
+    l2 = float(model.forward_backward(dict(batch)))
+    assert abs(l2 - float(loss)) < 1e-5 + 1e-5 * abs(l2)
     model.engine.check_errors()
 
 

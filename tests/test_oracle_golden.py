@@ -99,14 +99,13 @@ def test_out_of_table_entity_raises_keyerror(case):
             orc.forward(sd, cfg, table, **bad)
 
 
-def test_classification_head_matches_reference():
-    """G6: the reference's STonKGsForSequenceClassification.forward (single-label CE), ragged batch of 5, 3 classes."""
+def _cls_case(name):
     import json
     import os
 
-    with open(os.path.join(GOLDEN, "g6_classification.json")) as f:
+    with open(os.path.join(GOLDEN, name + ".json")) as f:
         meta = json.load(f)
-    gold = dict(np.load(os.path.join(GOLDEN, "g6_classification.npz")))
+    gold = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     cfg = orc.OracleConfig(**meta["config"])
     sd = orc.init_state_dict(cfg, seed=meta["weight_seed"])
     assert abs(float(sum(v.double().abs().sum() for v in sd.values())) - meta["weights_checksum"]) < 1e-6
@@ -116,6 +115,16 @@ def test_classification_head_matches_reference():
     sd["classifier.bias"] = (torch.randn(nl, generator=gw) * 0.02).to(torch.bfloat16).float()
     g = torch.Generator().manual_seed(meta["table_seed"])
     rows = torch.randn(cfg.kg_vocab_size, H, generator=g, dtype=torch.float64) * meta["table_std"]
+    return cfg, sd, rows, gold, meta
+
+
+@pytest.mark.parametrize("name", ["g6_classification", "g13_cls_regression_1d", "g14_cls_regression", "g15_cls_multilabel"])
+def test_classification_head_matches_reference(name):
+    """The reference's STonKGsForSequenceClassification.forward (ref:stonkgs_finetuning.py:259-346), its three loss
+    branches: G6 single-label CE (ragged batch of 5, 3 classes); G13 regression with num_labels = 1 and 1-D float labels
+    (MSELoss broadcasts [B,1] x [B] to [B,B] - the reference's own behaviour, restated as is); G14 regression over
+    [B,3]; G15 multi-label BCEWithLogitsLoss."""
+    cfg, sd, rows, gold, meta = _cls_case(name)
     with torch.no_grad():
         table = orc.build_kg_table(rows, orc.special_vectors(sd, cfg))
     names = [k for k in sd if k.startswith("bert.") and "word_embeddings" not in k] + ["classifier.weight", "classifier.bias"]
@@ -124,7 +133,8 @@ def test_classification_head_matches_reference():
     work.update(params)
     out = orc.forward_classification(work, cfg, table, torch.from_numpy(gold["input_ids"]),
                                      torch.from_numpy(gold["attention_mask"]), torch.from_numpy(gold["token_type_ids"]),
-                                     torch.from_numpy(gold["labels"]))
+                                     torch.from_numpy(gold["labels"]),
+                                     problem_type=meta.get("problem_type", "single_label_classification"))
     assert abs(float(out["loss"]) - float(gold["loss"])) < 1e-5
     np.testing.assert_allclose(out["logits"].detach().numpy(), gold["logits"], rtol=1e-4, atol=1e-5)
     out["loss"].backward()

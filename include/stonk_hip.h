@@ -224,9 +224,15 @@ int stonk_gelu_bwd_bf16(const void* dg, const void* u, void* du, int64_t n, void
  * fused clip_grad_norm_(max_grad_norm) + AdamW + bf16 weight refresh + grad zeroing. */
 int64_t stonk_sumsq_workspace_floats(void);
 int stonk_sumsq_f32(const float* x, int64_t n, float* out_accum, float* workspace, int64_t ws_floats, void* stream);
+/* stonk_adamw_step works on any piece of the flat buffers (pointers into p / g / p_bf16 at the piece, m / v wherever the
+ * caller keeps that piece's state: an optimizer sharded over data-parallel ranks updates its 1/world of every gradient
+ * bucket). decay_spans (nullable, device): n_spans sorted [lo, hi) element ranges of the WHOLE flat buffer that receive
+ * the decoupled weight decay (HF Trainer decays weights, not biases / LayerNorm); span_base = the piece's offset in the
+ * flat buffer (% 4 == 0). Without a table, weight_decay applies to every element. */
 int stonk_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, float bias_corr1, float bias_corr2, const float* gnorm_sq_dev,
-                     float max_grad_norm, float grad_scale, void* stream);
+                     float max_grad_norm, float grad_scale, const int64_t* decay_spans, int n_spans, int64_t span_base,
+                     void* stream);
 int stonk_scale_f32(float* x, int64_t n, float s, void* stream);
 
 #ifdef __cplusplus

@@ -72,7 +72,7 @@ _SIGNATURES = {
     "stonk_gelu_bwd_bf16": [_vp, _vp, _vp, _i64, _vp],
     "stonk_sumsq_f32": [_vp, _i64, _vp, _vp, _i64, _vp],
     "stonk_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _f32, _f32,
-                         _vp],
+                         _vp, _i32, _i64, _vp],
     "stonk_scale_f32": [_vp, _i64, _f32, _vp],
 }
 

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     float* __restrict__ v, bf16* __restrict__ pb, long n, float lr,
                                                     float b1, float b2, float eps, float wd, float bc1, float bc2,
                                                     const float* __restrict__ gnorm_sq, float max_norm,
-                                                    float grad_scale) {
+                                                    float grad_scale, const long* __restrict__ decay_spans,
+                                                    int n_spans, long span_base) {
   float coef = grad_scale;
   if (gnorm_sq && max_norm > 0.f) {
     // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
@@ -74,10 +75,24 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     f32x4 pp = *(f32x4*)(p + 4 * i), gg = *(f32x4*)(g + 4 * i), mm = *(f32x4*)(m + 4 * i), vv = *(f32x4*)(v + 4 * i);
     bf16x4 o;
+    // decoupled weight decay: everywhere (no table), or on the elements inside one of the sorted [lo, hi) spans of the
+    // flat buffer (HF Trainer's grouping: weights yes, biases and LayerNorm no). Tensors start at multiples of 256
+    // elements, so the four elements of a group share the answer.
+    float keep = 1.f - lr * wd;
+    if (decay_spans && wd != 0.f) {
+      const long e = span_base + 4 * i;
+      int lo = 0, hi = n_spans;
+      while (lo < hi) {   // last span whose start <= e
+        const int mid = (lo + hi) >> 1;
+        if (decay_spans[2 * mid] <= e) lo = mid + 1;
+        else hi = mid;
+      }
+      if (lo == 0 || e >= decay_spans[2 * (lo - 1) + 1]) keep = 1.f;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gr = gg[j] * coef;
-      float w = pp[j] * (1.f - lr * wd);
+      float w = pp[j] * keep;
       mm[j] = b1 * mm[j] + (1.f - b1) * gr;
       vv[j] = b2 * vv[j] + (1.f - b2) * gr * gr;
       const float denom = sqrtf(vv[j]) * inv_sqrt_bc2 + eps;
@@ -266,14 +281,16 @@ extern "C" int stonk_sumsq_f32(const float* x, int64_t n, float* out_accum, floa
 
 extern "C" int stonk_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
                                 float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
-                                const float* gnorm_sq_dev, float max_grad_norm, float grad_scale, void* stream) {
+                                const float* gnorm_sq_dev, float max_grad_norm, float grad_scale,
+                                const int64_t* decay_spans, int n_spans, int64_t span_base, void* stream) {
   STONK_CHECK_ARG(p && g && m && v && n >= 0 && n % 4 == 0, STONK_EINVAL);
+  STONK_CHECK_ARG(n_spans >= 0 && (decay_spans || n_spans == 0) && span_base >= 0 && span_base % 4 == 0, STONK_EINVAL);
   STONK_CHECK_ARG(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, STONK_EALIGN);
   STONK_CHECK_ARG(bias_corr1 > 0.f && bias_corr2 > 0.f, STONK_EINVAL);
   if (n == 0) return STONK_OK;
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16,
                      (long)n, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, gnorm_sq_dev, max_grad_norm,
-                     grad_scale);
+                     grad_scale, (const long*)decay_spans, n_spans, (long)span_base);
   return stonk_launch_status();
 }
 

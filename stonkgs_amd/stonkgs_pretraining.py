@@ -50,6 +50,11 @@ class TrainingArguments:
     optimizer_overlap: bool = True
     # run the gradient collectives even when the process group has a single rank (hardware rehearsal of the N > 1 path)
     ddp_force_collectives: bool = False
+    # ZeRO-2-style optimizer sharding (the reference can run DeepSpeed ZeRO-2: ref:stonkgs_pretraining.py:174-175): every
+    # gradient bucket is reduce-SCATTERED instead of all-reduced, each rank keeps Adam's m / v for - and updates - its
+    # 1/world piece of every bucket only, and the updated fp32 parameters are all-gathered (same bytes on the wire as the
+    # all-reduce; AdamW's 30 B/param of HBM traffic and the optimizer state shrink by the world size)
+    shard_optimizer: bool = False
 
 
 def linear_schedule_lr(base_lr: float, step: int, max_steps: int, warmup: int = 0) -> float:
@@ -60,37 +65,79 @@ def linear_schedule_lr(base_lr: float, step: int, max_steps: int, warmup: int = 
 
 
 class FusedAdamW:
-    """clip_grad_norm_ + AdamW + zero_grad over the model's flat fp32 buffers in two kernel launches."""
+    """clip_grad_norm_ + AdamW + zero_grad over the model's flat fp32 buffers in two kernel launches - or, with `spans`
+    (optimizer sharding: the [lo, hi) pieces of the flat buffer this rank owns), the same per piece with m / v stored for
+    the owned pieces only."""
 
-    def __init__(self, store: FlatStore, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0):
+    def __init__(self, store: FlatStore, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0,
+                 spans: Optional[List[tuple]] = None):
         self.store = store
         self.betas, self.eps, self.weight_decay, self.max_grad_norm = betas, eps, weight_decay, max_grad_norm
         # HF Trainer decays every parameter except biases and LayerNorm weights (hf:trainer.py get_decay_parameter_names);
         # the reference trains with weight_decay = 0, so this only matters to a caller who sets it
         self.decayed = [name for name in store.index if name.endswith(".weight") and "LayerNorm" not in name]
-        self.m = torch.zeros_like(store.data)
-        self.v = torch.zeros_like(store.data)
-        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=store.data.device)
+        self.spans = None if spans is None else [(int(lo), int(hi)) for lo, hi in spans if hi > lo]
+        n_state = store.numel if self.spans is None else sum(hi - lo for lo, hi in self.spans)
+        dev = store.data.device
+        self.m = torch.zeros(n_state, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n_state, dtype=torch.float32, device=dev)
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         # partial sums + ticket of the fixed-order grad-norm reduction (zeroed once; the kernel leaves it ready)
-        self.norm_ws = torch.zeros(int(hip.lib().stonk_sumsq_workspace_floats()), dtype=torch.float32,
-                                   device=store.data.device)
+        self.norm_ws = torch.zeros(int(hip.lib().stonk_sumsq_workspace_floats()), dtype=torch.float32, device=dev)
         self.step_count = 0
+        self._decay_spans = None   # device [n, 2] int64 of the decayed tensors' [lo, hi) offsets (built on first use)
+
+    def _pieces(self):
+        """(offset in the flat buffers, offset in m / v, length) of every piece this rank updates."""
+        if self.spans is None:
+            return [(0, 0, self.store.numel)]
+        out, acc = [], 0
+        for lo, hi in self.spans:
+            out.append((lo, acc, hi - lo))
+            acc += hi - lo
+        return out
+
+    def accumulate_grad_norm_sq(self) -> None:
+        """gnorm_sq = sum of squares of the gradient over this rank's pieces (the whole buffer without sharding) - in a
+        fixed order, so that replicas holding the same gradients get the same bits."""
+        s, st = self.store, hip.stream_ptr()
+        self.gnorm_sq.zero_()
+        for off, _, n in self._pieces():
+            hip.call("stonk_sumsq_f32", s.grad.data_ptr() + 4 * off, n, self.gnorm_sq.data_ptr(), self.norm_ws.data_ptr(),
+                     self.norm_ws.numel(), st)
+
+    def _decay_table(self):
+        if self._decay_spans is None:
+            s = self.store
+            rows = []
+            for name in self.decayed:
+                off, _, pshape = s.index[name]
+                n = 1
+                for d in pshape:
+                    n *= d
+                rows.append((off, off + n))
+            rows.sort()
+            self._decay_spans = torch.tensor(rows, dtype=torch.int64, device=s.data.device).reshape(-1, 2)
+        return self._decay_spans
+
+    def apply_update(self, lr: float, grad_scale: float = 1.0) -> None:
+        """clip (from gnorm_sq) + AdamW + bf16 mirror + gradient zeroing over this rank's pieces. Decoupled weight decay
+        (p *= 1 - lr * wd on the decayed tensors only: torch.optim.AdamW's order) happens inside the same kernel, from a
+        device table of the decayed tensors' spans."""
+        s, st = self.store, hip.stream_ptr()
+        b1, b2 = self.betas
+        wd = float(self.weight_decay)
+        tab = self._decay_table() if wd else None
+        for off, soff, n in self._pieces():
+            hip.call("stonk_adamw_step", s.data.data_ptr() + 4 * off, s.grad.data_ptr() + 4 * off,
+                     self.m.data_ptr() + 4 * soff, self.v.data_ptr() + 4 * soff, s.bf16.data_ptr() + 2 * off, n, lr, b1, b2,
+                     self.eps, wd, 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count, self.gnorm_sq.data_ptr(),
+                     self.max_grad_norm, grad_scale, hip.ptr(tab), 0 if tab is None else tab.shape[0], off, st)
 
     def step(self, lr: float, grad_scale: float = 1.0) -> None:
-        s = self.store
-        st = hip.stream_ptr()
         self.step_count += 1
-        b1, b2 = self.betas
-        self.gnorm_sq.zero_()
-        hip.call("stonk_sumsq_f32", s.grad.data_ptr(), s.numel, self.gnorm_sq.data_ptr(), self.norm_ws.data_ptr(),
-                 self.norm_ws.numel(), st)
-        if self.weight_decay:   # decoupled decay, p *= 1 - lr * wd, on the decayed tensors only and before the Adam update
-            for name in self.decayed:   # (torch.optim.AdamW's order); the fused kernel below then runs with wd = 0
-                v = s.view(name, padded=True)
-                hip.call("stonk_scale_f32", v.data_ptr(), v.numel(), 1.0 - lr * self.weight_decay, st)
-        hip.call("stonk_adamw_step", s.data.data_ptr(), s.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                 s.bf16.data_ptr(), s.numel, lr, b1, b2, self.eps, 0.0, 1.0 - b1 ** self.step_count,
-                 1.0 - b2 ** self.step_count, self.gnorm_sq.data_ptr(), self.max_grad_norm, grad_scale, st)
+        self.accumulate_grad_norm_sq()
+        self.apply_update(lr, grad_scale)
 
     def last_grad_norm(self, grad_scale: float = 1.0) -> float:
         torch.cuda.synchronize(self.gnorm_sq.device)   # the optimizer may have run on its own stream
@@ -100,10 +147,12 @@ class FusedAdamW:
         self.store.grad.zero_()
 
     def state_dict(self):
-        return {"step": self.step_count, "m": self.m.cpu(), "v": self.v.cpu()}
+        return {"step": self.step_count, "m": self.m.cpu(), "v": self.v.cpu(), "spans": self.spans}
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
+        if tuple(sd["m"].shape) != tuple(self.m.shape):
+            raise ValueError("optimizer state was saved under a different sharding (world size / shard_optimizer)")
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
 

@@ -232,7 +232,7 @@ def test_adamw_matches_torch(hip, clip):
         hip.call("stonk_sumsq_f32", hip.ptr(gg), n, hip.ptr(nrm), hip.ptr(ws), ws.numel(), hip.stream_ptr())
         torch.testing.assert_close(nrm[0], (g.double() ** 2).sum().float(), rtol=1e-5, atol=0)
         hip.call("stonk_adamw_step", hip.ptr(p), hip.ptr(gg), hip.ptr(m), hip.ptr(v), hip.ptr(pb), n, 1e-3, 0.9, 0.999,
-                 1e-8, 0.01, 1 - 0.9 ** step, 1 - 0.999 ** step, hip.ptr(nrm), 1.0, 1.0, hip.stream_ptr())
+                 1e-8, 0.01, 1 - 0.9 ** step, 1 - 0.999 ** step, hip.ptr(nrm), 1.0, 1.0, 0, 0, 0, hip.stream_ptr())
         assert (gg == 0).all()  # zero_grad fused
         torch.testing.assert_close(p, ref_p.data, rtol=2e-5, atol=2e-7)
         assert torch.equal(pb, p.to(torch.bfloat16))

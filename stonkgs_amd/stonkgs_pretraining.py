@@ -146,15 +146,29 @@ class FusedAdamW:
     def zero_grad(self) -> None:
         self.store.grad.zero_()
 
-    def state_dict(self):
-        return {"step": self.step_count, "m": self.m.cpu(), "v": self.v.cpu(), "spans": self.spans}
+    def state_dict(self, sync=None):
+        """Adam's state in the flat buffer's layout, whatever the sharding: with a sharded optimizer the pieces are
+        all-gathered through `sync` first (a collective: every rank calls it), so a checkpoint written under one world
+        size loads under another."""
+        if self.spans is None:
+            return {"step": self.step_count, "m": self.m.cpu(), "v": self.v.cpu()}
+        full = {}
+        for key, src in (("m", self.m), ("v", self.v)):
+            buf = torch.zeros(self.store.numel, dtype=torch.float32, device=src.device)
+            for off, soff, n in self._pieces():
+                buf[off:off + n].copy_(src[soff:soff + n])
+            sync.gather_params(buf)
+            full[key] = buf.cpu()
+        return {"step": self.step_count, **full}
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
-        if tuple(sd["m"].shape) != tuple(self.m.shape):
-            raise ValueError("optimizer state was saved under a different sharding (world size / shard_optimizer)")
-        self.m.copy_(sd["m"])
-        self.v.copy_(sd["v"])
+        if sd["m"].numel() != self.store.numel:
+            raise ValueError("optimizer state does not match this model's flat parameter layout")
+        for key, dst in (("m", self.m), ("v", self.v)):
+            src = sd[key]
+            for off, soff, n in self._pieces():
+                dst[soff:soff + n].copy_(src[off:off + n])
 
 
 def plan_buckets(segment_ends: List[int], bucket_elems: int) -> List[tuple]:
@@ -177,10 +191,18 @@ class GradSynchronizer:
     "segment X done" every byte before X's end is final: the bucket ending there is all-reduced immediately, on
     RCCL's own stream, while the compute stream continues with the next layer's backward. xGMI is point-to-point
     (7 links/GPU), so few large buckets (default 64 MB) beat DDP's 25 MB default. Averaging is folded into the
-    optimizer kernel's grad_scale (sum here, 1/world there)."""
+    optimizer kernel's grad_scale (sum here, 1/world there).
+
+    `shard=True` (TrainingArguments.shard_optimizer; ZeRO-2 as the reference can run it through DeepSpeed,
+    ref:stonkgs_pretraining.py:174-175): every bucket is cut into `world` equal pieces, rank r owns piece r of EVERY bucket
+    (so its share becomes final bucket by bucket, like the buckets themselves), the collective is a reduce-scatter into the
+    owned piece, the optimizer updates the owned pieces only (`owned_spans`) and `gather_params` all-gathers the updated
+    fp32 parameters bucket by bucket: the same bytes on the wire as the all-reduce, 1/world of AdamW's HBM traffic and of
+    Adam's state. Buckets end at tensor boundaries, which are multiples of 256 elements (params.ALIGN): any world size
+    that divides 64 cuts them into 16-byte aligned pieces."""
 
     def __init__(self, grad: torch.Tensor, segments: Dict[str, int], bucket_mb: float = 64.0, group=None,
-                 force: bool = False):
+                 force: bool = False, shard: bool = False):
         """`force`: issue the collectives even in a one-rank group (a sum over one rank: the values do not change) - lets
         a one-GPU box execute the RCCL path, its stream ordering and the kernel routing that goes with it."""
         import torch.distributed as dist
@@ -189,12 +211,40 @@ class GradSynchronizer:
         self.grad = grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.active = self.world > 1 or (force and dist.is_initialized())
         self.segment_end = dict(segments)  # notification name -> end offset in the flat buffer
         ends = sorted(set(segments.values()))
         self.buckets = plan_buckets(ends, int(bucket_mb * (1 << 20) / 4))
+        self.shard = bool(shard) and self.active
+        if self.shard:
+            bad = [(lo, hi) for lo, hi in self.buckets if (hi - lo) % (4 * self.world)]
+            if bad:
+                raise ValueError(f"shard_optimizer: world size {self.world} does not cut bucket {bad[0]} into 16-byte "
+                                 "aligned pieces (tensors start at multiples of 256 elements: use a world size dividing 64)")
+            # gloo (CPU tests, several ranks on one card) has no reduce-scatter: an all-reduce leaves the sum in the owned
+            # piece as well - same result, more bytes, never a measurement
+            self._has_rs = dist.get_backend(group) == "nccl"
         self._next = 0
         self._works = []
+
+    def owned_spans(self) -> Optional[List[tuple]]:
+        """[lo, hi) pieces of the flat buffers this rank reduces into and updates; None when the optimizer is replicated."""
+        if not self.shard:
+            return None
+        out = []
+        for lo, hi in self.buckets:
+            piece = (hi - lo) // self.world
+            out.append((lo + self.rank * piece, lo + (self.rank + 1) * piece))
+        return out
+
+    def _launch(self, lo: int, hi: int):
+        d = self.dist
+        if self.shard and self._has_rs:
+            piece = (hi - lo) // self.world
+            mine = self.grad[lo + self.rank * piece: lo + (self.rank + 1) * piece]   # in place: output = own slice of input
+            return d.reduce_scatter_tensor(mine, self.grad[lo:hi], op=d.ReduceOp.SUM, group=self.group, async_op=True)
+        return d.all_reduce(self.grad[lo:hi], op=d.ReduceOp.SUM, group=self.group, async_op=True)
 
     def on_segment_done(self, name: str) -> None:
         if not self.active:
@@ -203,23 +253,41 @@ class GradSynchronizer:
         if end is None:
             return
         while self._next < len(self.buckets) and self.buckets[self._next][1] <= end:
-            lo, hi = self.buckets[self._next]
-            self._works.append(self.dist.all_reduce(self.grad[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group,
-                                                    async_op=True))
+            self._works.append(self._launch(*self.buckets[self._next]))
             self._next += 1
 
     def finish(self) -> float:
         """Flush remaining buckets, wait for all of them; returns the factor that turns the sum into the mean."""
         if self.active:
             while self._next < len(self.buckets):
-                lo, hi = self.buckets[self._next]
-                self._works.append(self.dist.all_reduce(self.grad[lo:hi], op=self.dist.ReduceOp.SUM,
-                                                        group=self.group, async_op=True))
+                self._works.append(self._launch(*self.buckets[self._next]))
                 self._next += 1
             for w in self._works:
                 w.wait()
         self._works, self._next = [], 0
         return 1.0 / self.world
+
+    def all_reduce_scalar(self, t: torch.Tensor) -> None:
+        """Sum a small tensor over the ranks (the sharded grad-norm: every rank holds the squares of its pieces)."""
+        if self.shard:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def gather_params(self, flat: torch.Tensor) -> None:
+        """Sharded optimizer: every rank has updated its piece of every bucket of `flat` (the fp32 parameters, or any
+        buffer with the gradient's layout); all-gather the pieces in place, bucket by bucket."""
+        if not self.shard:
+            return
+        d, works = self.dist, []
+        for lo, hi in self.buckets:
+            piece = (hi - lo) // self.world
+            mine = flat[lo + self.rank * piece: lo + (self.rank + 1) * piece]
+            if self._has_rs:
+                works.append(d.all_gather_into_tensor(flat[lo:hi], mine, group=self.group, async_op=True))
+            else:   # gloo: list form, into the bucket's own pieces
+                outs = [flat[lo + r * piece: lo + (r + 1) * piece] for r in range(self.world)]
+                works.append(d.all_gather(outs, mine.clone(), group=self.group, async_op=True))
+        for w in works:
+            w.wait()
 
 
 def segment_ends_for(model) -> Dict[str, int]:
@@ -250,12 +318,12 @@ class Trainer:
         self.args = args or TrainingArguments()
         self.train_dataset = train_dataset
         self.data_collator = data_collator
-        self.optimizer = FusedAdamW(model._store, (self.args.adam_beta1, self.args.adam_beta2), self.args.adam_epsilon,
-                                    self.args.weight_decay, self.args.max_grad_norm)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.sync = GradSynchronizer(model._store.grad, segment_ends_for(model), self.args.ddp_bucket_mb,
-                                     force=self.args.ddp_force_collectives)
+                                     force=self.args.ddp_force_collectives, shard=self.args.shard_optimizer)
+        self.optimizer = FusedAdamW(model._store, (self.args.adam_beta1, self.args.adam_beta2), self.args.adam_epsilon,
+                                    self.args.weight_decay, self.args.max_grad_norm, spans=self.sync.owned_spans())
         model.engine.comm_overlap = self.sync.active   # (see Engine.comm_overlap)
         self.global_step = 0
         self._micro = 0
@@ -273,8 +341,15 @@ class Trainer:
             lr = linear_schedule_lr(self.args.learning_rate, self.global_step, self.args.max_steps, self.args.warmup_steps)
             with model.engine.optimizer_stream(self.args.optimizer_overlap):
                 scale = self.sync.finish()
-                self.optimizer.step(lr, grad_scale=scale)
-                model.engine.refresh_derived(bf16_mirror=False)
+                opt = self.optimizer
+                opt.step_count += 1
+                opt.accumulate_grad_norm_sq()               # replicated: the whole buffer; sharded: this rank's pieces ...
+                self.sync.all_reduce_scalar(opt.gnorm_sq)   # ... summed over the ranks (a no-op when replicated)
+                opt.apply_update(lr, grad_scale=scale)
+                if self.sync.shard:
+                    model._store.grad.zero_()               # (the kernel zeroed the owned pieces only)
+                    self.sync.gather_params(model._store.data)
+                model.engine.refresh_derived(bf16_mirror=self.sync.shard)   # sharded: the bf16 mirror of the gathered pieces too
             self.global_step += 1
         return loss
 
@@ -310,16 +385,19 @@ class Trainer:
                 if self.global_step % self.args.logging_steps == 0 or self.global_step == self.args.max_steps:
                     self.model.engine.check_errors()
                     self.log_history.append({"step": self.global_step, "loss": float(loss), "time": time.time() - t0})
-                if self.args.save_steps and self.global_step % self.args.save_steps == 0 and self.rank == 0:
-                    self.save_checkpoint()
+                if self.args.save_steps and self.global_step % self.args.save_steps == 0:
+                    self.save_checkpoint()   # (every rank: a sharded optimizer gathers its state; rank 0 writes)
         return {"global_step": self.global_step, "training_loss": float(loss)}
 
     # checkpoint / resume (ref:stonkgs_pretraining.py:185-186,196-223: save_steps, save_total_limit, resume)
     def save_checkpoint(self) -> str:
         self.model.engine.wait_params()
         d = os.path.join(self.args.output_dir, f"checkpoint-{self.global_step}")
+        opt_state = self.optimizer.state_dict(self.sync)
+        if self.rank != 0:
+            return d
         self.model.save_pretrained(d)
-        torch.save(self.optimizer.state_dict(), os.path.join(d, "optimizer.pt"))
+        torch.save(opt_state, os.path.join(d, "optimizer.pt"))
         with open(os.path.join(d, "trainer_state.json"), "w") as fh:
             json.dump({"global_step": self.global_step, "log_history": self.log_history, "args": asdict(self.args),
                        "dropout_counter": int(self.model.engine.seed_base)}, fh)

@@ -279,6 +279,9 @@ def test_attention_packed_sequences_of_any_length(hip, drop_p):
         torch.testing.assert_close(out[rows].float(), o_ref, rtol=2e-2, atol=2e-2)
         torch.testing.assert_close(lse[b, :, :n], lse_ref[0], rtol=1e-4, atol=2e-3)
         for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+            if float(g_ref[:, sl].abs().max()) == 0.0:   # (one key: P = 1, dS = 0 - dQ and dK are exactly zero)
+                assert float(dqkv[rows, sl].float().abs().max()) < 1e-3, (b, n, name)
+                continue
             e = _relerr(dqkv[rows, sl], g_ref[:, sl])
             assert e < 2e-2, (b, n, name, e)
     assert float(dqkv[150:167, H:].abs().max()) == 0.0     # masked rows: no key / value gradient

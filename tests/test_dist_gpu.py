@@ -45,10 +45,10 @@ def test_rccl_path_executes_in_a_one_rank_group(hip):
 
     init = STonKGsForPreTraining(cfg, kg_embeddings=table, seed=0)._store.data.detach().clone()
 
-    def run(force):
+    def run(force, shard=False):
         model = STonKGsForPreTraining(cfg, kg_embeddings=table, seed=0)
         tr = Trainer(model, TrainingArguments(learning_rate=1e-3, max_steps=10, per_device_train_batch_size=B,
-                                              ddp_bucket_mb=8, ddp_force_collectives=force))
+                                              ddp_bucket_mb=8, ddp_force_collectives=force, shard_optimizer=shard))
         model.engine.comm_overlap = True        # same kernel routing in both arms
         losses = [float(tr.training_step(model, b)) for b in batches]
         model.engine.check_errors()
@@ -68,6 +68,10 @@ def test_rccl_path_executes_in_a_one_rank_group(hip):
         assert tr1.sync.active and len(tr1.sync.buckets) >= 3 and dist.get_backend() == "nccl"
         l0, p0, tr0 = run(False)
         assert not tr0.sync.active
+        # the sharded optimizer over RCCL in the one-rank group: reduce_scatter_tensor into the (whole-bucket) owned piece,
+        # per-piece AdamW, all_gather_into_tensor in place, bf16 mirror rebuilt from the gathered parameters
+        l2, p2, tr2 = run(True, shard=True)
+        assert tr2.sync.shard and tr2.optimizer.spans == [(lo, hi) for lo, hi in tr2.sync.buckets]
     finally:
         dist.destroy_process_group()
     assert l1 == pytest.approx(l0, rel=1e-5)
@@ -77,11 +81,23 @@ def test_rccl_path_executes_in_a_one_rank_group(hip):
     moved1, moved0 = p1 - init, p0 - init
     cos = torch.nn.functional.cosine_similarity(moved1.flatten(), moved0.flatten(), dim=0).item()
     assert float(d.max()) <= 2.1e-3 and cos > 0.999, (float(d.max()), cos)
+    assert l2 == pytest.approx(l0, rel=1e-5)
+    cos2 = torch.nn.functional.cosine_similarity((p2 - init).flatten(), moved0.flatten(), dim=0).item()
+    assert float((p2 - p0).abs().max()) <= 2.1e-3 and cos2 > 0.999, (float((p2 - p0).abs().max()), cos2)
 
 
 def test_two_ranks_on_one_gpu_over_gloo(hip):
     r = _ranks(2, "tools/dp_check.py", env={"STONK_DIST_BACKEND": "gloo"})
     assert r.returncode == 0 and "DP2 OK (gloo)" in r.stdout[0], r.tail()
+    assert "gradient buffer after the collectives" in r.stderr[0]      # (check A ran: bucket boundaries)
+
+
+def test_two_ranks_on_one_gpu_with_a_sharded_optimizer(hip):
+    """TrainingArguments.shard_optimizer (ZeRO-2, as the reference can run it: ref:stonkgs_pretraining.py:174-175): each rank
+    reduces into and updates its half of every bucket, the parameters are all-gathered; replicas bitwise identical and
+    equal to the single-process run, as without sharding."""
+    r = _ranks(2, "tools/dp_check.py", env={"STONK_DIST_BACKEND": "gloo", "STONK_DP_SHARD": "1"})
+    assert r.returncode == 0 and "DP2 OK (gloo, sharded optimizer)" in r.stdout[0], r.tail()
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")

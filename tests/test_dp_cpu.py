@@ -111,3 +111,66 @@ def test_launcher_stops_the_peers_of_a_dead_rank():
     r = _probe("die", timeout=120, peer_grace=1.0)
     assert r.returncode == 7 and not r.timed_out and r.codes[0] == 7 and r.codes[1] != 0
     assert time.time() - t0 < 30
+
+
+# ---- optimizer sharding (TrainingArguments.shard_optimizer): reduce into the owned piece of every bucket, update it,
+# all-gather the parameters - world 2 over gloo
+def _shard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 8192
+        segments = {"a": 2048, "b": 2560, "c": 6144, "d": n}          # tensor boundaries: multiples of 256
+        for step in range(2):
+            g_local = [torch.arange(n, dtype=torch.float32) * (r + 1) + step for r in range(world)]
+            grad = g_local[rank].clone()
+            sync = GradSynchronizer(grad, segments, bucket_mb=2048 * 4 / (1 << 20), shard=True)
+            assert sync.shard and sync.buckets == plan_buckets([2048, 2560, 6144, n], 2048)
+            spans = sync.owned_spans()
+            assert len(spans) == len(sync.buckets)
+            for (lo, hi), (blo, bhi) in zip(spans, sync.buckets):
+                piece = (bhi - blo) // world
+                assert (lo, hi) == (blo + rank * piece, blo + (rank + 1) * piece)
+            for name in ("a", "b", "c"):
+                sync.on_segment_done(name)
+            scale = sync.finish()
+            total = sum(g_local)
+            ok = scale == 1.0 / world
+            for lo, hi in spans:                                       # the owned pieces hold the sum over the ranks
+                ok = ok and torch.equal(grad[lo:hi], total[lo:hi])
+            # grad-norm: squares of the owned pieces, summed over the ranks = the whole buffer's
+            sq = torch.stack([(grad[lo:hi].double() ** 2).sum() for lo, hi in spans]).sum().reshape(1)
+            sync.all_reduce_scalar(sq)
+            ok = ok and abs(float(sq) - float((total.double() ** 2).sum())) <= 1e-9 * float(sq)
+            # "optimizer": every rank updates ITS pieces of the parameters, then the pieces are gathered
+            params = torch.full((n,), 5.0)
+            for lo, hi in spans:
+                params[lo:hi] -= 0.5 * scale * grad[lo:hi]
+            sync.gather_params(params)
+            ok = ok and torch.equal(params, 5.0 - 0.5 * scale * total)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_optimizer_collectives_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_sharding_refuses_a_world_size_that_cuts_unaligned_pieces(monkeypatch):
+    import torch.distributed as d
+
+    monkeypatch.setattr(d, "is_initialized", lambda: True)
+    monkeypatch.setattr(d, "get_world_size", lambda group=None: 3)
+    monkeypatch.setattr(d, "get_rank", lambda group=None: 0)
+    with pytest.raises(ValueError, match="world size 3"):
+        GradSynchronizer(torch.zeros(4096), {"a": 2048, "b": 4096}, bucket_mb=1e-9, shard=True)

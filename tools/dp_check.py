@@ -9,8 +9,12 @@ one session per rank, logs in files); `python -m torch.distributed.run --nnodes=
 A rank that stalls says where: every phase is announced on stderr, rendezvous and collectives carry a 120-s limit (an
 error, not a silent wait), and after STONK_DP_CHECK_DUMP_AFTER seconds (default 200) every thread's Python stack is written
 to stderr - the launcher keeps the ranks' output in files, so it survives the kill that follows.
-Checks: both ranks end with bitwise-identical parameters; they match a single-process run that accumulates the two
-ranks' batches (DDP semantics: mean over ranks of per-rank mean losses) within fp32 round-off of the atomics."""
+Checks: (A) the synchronised GRADIENT buffer - every bucket after `finish()`, before any optimizer touches it - equals the
+sum of the ranks' single-process gradients to fp32 round-off (1e-5 of the largest gradient: a bucket boundary off by a few
+thousand elements leaves them at half their value); (B) after two training steps both ranks hold bitwise-identical
+parameters, and they match a single-process run that accumulates the two ranks' batches (DDP semantics: mean over ranks
+of per-rank mean losses) within what Adam makes of fp32 round-off. STONK_DP_SHARD=1 runs the same with the optimizer
+sharded (reduce-scatter into the owned piece of every bucket, sharded AdamW, all-gather of the parameters)."""
 import faulthandler
 import os
 import sys
@@ -57,9 +61,41 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     say("process group up; building the model")
     B = 32
+    shard = os.environ.get("STONK_DP_SHARD") == "1"
     cfg, model = build()
-    tr = Trainer(model, TrainingArguments(learning_rate=1e-3, max_steps=10, per_device_train_batch_size=B, ddp_bucket_mb=8))
-    assert tr.world == world and model.engine.comm_overlap == (world > 1)
+    tr = Trainer(model, TrainingArguments(learning_rate=1e-3, max_steps=10, per_device_train_batch_size=B, ddp_bucket_mb=8,
+                                          shard_optimizer=shard))
+    assert tr.world == world and model.engine.comm_overlap == (world > 1) and tr.sync.shard == (shard and world > 1)
+    # ---- (A) the gradient buffer after the collectives, against the sum of single-process gradients
+    model.train()
+    model.forward_backward(synthetic_batch(B, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=90 + rank),
+                           on_segment_done=tr.sync.on_segment_done)
+    tr.sync.finish()
+    torch.cuda.synchronize()
+    got = model._store.grad.detach().clone()
+    model._store.grad.zero_()
+    ref = torch.zeros_like(got)
+    if rank == 0:
+        _, solo = build()
+        solo.train()
+        solo.engine.comm_overlap = False
+        for r in range(world):
+            solo.forward_backward(synthetic_batch(B, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=90 + r))
+        solo.engine.join_wgrad()
+        torch.cuda.synchronize()
+        ref.copy_(solo._store.grad)
+        del solo
+    dist.broadcast(ref, src=0)
+    spans = tr.sync.owned_spans() or [(0, got.numel())]
+    gmax = float(ref.abs().max())
+    worst = max(float((got[lo:hi] - ref[lo:hi]).abs().max()) for lo, hi in spans)
+    say(f"gradient buffer after the collectives: max |dp - sum of single-process gradients| = {worst:.3e} "
+        f"(largest gradient {gmax:.3e}; {len(spans)} span(s) checked)")
+    grads_ok = worst <= 1e-5 * gmax
+    flag = torch.tensor([1.0 if grads_ok else 0.0])
+    dist.all_reduce(flag.to(got.device) if backend == "nccl" else flag, op=dist.ReduceOp.MIN)
+    assert grads_ok, (worst, gmax)
+    # ---- (B) two training steps
     losses = []
     for step in range(2):
         b = synthetic_batch(B, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=100 + 10 * step + rank)
@@ -89,8 +125,8 @@ def main():
         # single process, the same 2 x 2 batches with gradient accumulation over the "ranks"
         cfg2, ref = build()
         tr2 = Trainer(ref, TrainingArguments(learning_rate=1e-3, max_steps=10, per_device_train_batch_size=B,
-                                             gradient_accumulation_steps=world))
-        tr2.world, tr2.sync.world, tr2.sync.active = 1, 1, False
+                                             gradient_accumulation_steps=world, ddp_force_collectives=False))
+        tr2.world, tr2.sync.world, tr2.sync.active, tr2.sync.shard = 1, 1, False, False
         ref.engine.comm_overlap = False
         for step in range(2):
             for r in range(world):
@@ -100,7 +136,7 @@ def main():
         scale = (ref._store.data.abs().max().item())
         print(f"ranks identical: {same}; losses {losses}; max |dp - accumulated| = {d:.3e} (param scale {scale:.2f})", flush=True)
         assert same and d < 2e-3, (same, d)
-        print(f"DP{world} OK ({backend})", flush=True)
+        print(f"DP{world} OK ({backend}{', sharded optimizer' if shard else ''})", flush=True)
     say("final barrier")
     dist.barrier()
     dist.destroy_process_group()

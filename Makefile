@@ -15,6 +15,25 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_common.h $(CSRC)/stonk_
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
+# Host-side AddressSanitizer build of the launchers (CPU only: the device code is compiled as usual, the host code -
+# argument validation, launch geometry, descriptor handling - is instrumented). Load it with the sanitizer runtime
+# preloaded: tests/test_host_cpu.py::test_asan_host_build_of_the_launchers does.
+ASAN_DIR := build/asan
+ASAN_OBJS := $(patsubst $(CSRC)/%.hip,$(ASAN_DIR)/%.o,$(SRCS))
+ASAN_LIB := $(ASAN_DIR)/libstonk_hip_asan.so
+ASANFLAGS := --offload-arch=$(ARCH) -O1 -g -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wno-unused-result -ffp-contract=fast \
+             -Xarch_host -fsanitize=address -Xarch_host -fno-omit-frame-pointer
+
+$(ASAN_DIR)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_common.h $(CSRC)/stonk_flags.h include/stonk_hip.h
+	@mkdir -p $(ASAN_DIR)
+	$(HIPCC) $(ASANFLAGS) -c $< -o $@
+
+$(ASAN_LIB): $(ASAN_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Xarch_host -fsanitize=address -shared-libsan -o $@ $(ASAN_OBJS)
+
+asan: $(ASAN_LIB)
+
 clean:
 	rm -f $(OBJS) $(LIB)
-.PHONY: all clean
+	rm -rf $(ASAN_DIR)
+.PHONY: all clean asan

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libstonk_hip.so")
+# (STONK_HIP_LIB: a differently built copy of the SAME library - the host-side AddressSanitizer build of `make asan`)
+LIB_PATH = os.environ.get("STONK_HIP_LIB") or os.path.join(_HERE, "csrc", "libstonk_hip.so")
 
 # ---- flags (mirror of csrc/stonk_flags.h) ----
 EPI_OUT_BF16 = 0

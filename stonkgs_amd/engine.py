@@ -118,6 +118,9 @@ class Engine:
         # side-stream weight gradients
         self.tn_v1 = bool(os.environ.get("STONK_TN_V1"))
         self.tn_cus = int(os.environ.get("STONK_TN_CUS", "160"))
+        # roctx ranges around the blocks of SURVEY section 2.3 (K1 backbone ... K16 optimizer), so that a
+        # `rocprofv3 --marker-trace --kernel-trace` timeline reads by block. Off unless STONK_ROCTX=1 (read once, here).
+        self.roctx = bool(os.environ.get("STONK_ROCTX"))
         self.tn_min_tiles = 36    # 128x128 tiles of an output from which the four-wave kernel takes the gradient: 36 = the
                                   # 768 x 768 ones too (35.67 against 35.79 ms per step with 100, tools/sweep_engine_int.py)
 
@@ -147,6 +150,18 @@ class Engine:
             ev = torch.cuda.Event()
             ev.record(self._opt_stream)
         self._params_ready = ev
+
+    @contextlib.contextmanager
+    def block(self, name: str):
+        """roctx range (torch.cuda.nvtx maps to roctx on ROCm) around one block of the step; a no-op unless `roctx`."""
+        if not self.roctx:
+            yield
+            return
+        torch.cuda.nvtx.range_push(name)
+        try:
+            yield
+        finally:
+            torch.cuda.nvtx.range_pop()
 
     def wait_params(self) -> None:
         """Order the current stream after the last optimizer step, if it ran on the optimizer stream (no host
@@ -263,9 +278,9 @@ class Engine:
         if bf16_mirror:
             for s in (self.P, self.BB):
                 hip.call("stonk_cast_f32_to_bf16", s.data.data_ptr(), s.bf16.data_ptr(), s.numel, st)
-        if self._wt_desc is None:
+        if self._wt_desc is None or self._wt_desc[3] != self.P.bf16.data_ptr():   # (the table holds raw addresses)
             self._wt_desc = self._build_wt_table()
-        desc, n, tiles = self._wt_desc
+        desc, n, tiles, _ = self._wt_desc
         hip.call("stonk_transpose_bf16_batched", desc.data_ptr(), n, tiles, st)
 
     def _build_wt_table(self):
@@ -287,11 +302,15 @@ class Engine:
                 wt = torch.zeros(cols, rpad, dtype=BF16, device=self.device)
                 self.P.wt[name] = wt
             src = self.P.bf16_view(name, padded=False)
+            # the kernel moves 16-byte vectors and cannot validate a device-side table: what it assumes is checked here
+            if cols % 8 or src.data_ptr() % 16 or wt.data_ptr() % 16 or rpad % 8 or wt.shape[1] < (rows + 63) // 64 * 64:
+                raise ValueError(f"{name}: [{rows}, {cols}] cannot take the batched W^T refresh (needs cols % 8 == 0, "
+                                 "16-byte aligned slices and a destination of roundup64(rows) columns)")
             col_tiles = (cols + 63) // 64
             entries.append(struct.pack("<QQqqqiiii", src.data_ptr(), wt.data_ptr(), cols, rpad, rows, cols, first, col_tiles, 0))
             first += ((rows + 63) // 64) * col_tiles
         raw = torch.frombuffer(bytearray(b"".join(entries)), dtype=torch.uint8).to(self.device)
-        return raw, len(entries), first
+        return raw, len(entries), first, self.P.bf16.data_ptr()
 
     # ------------------------------------------------------------------ one BERT layer
     def layer_fwd(self, S: FlatStore, prefix: str, x, B, seq, mask, p_hid, p_att, lidx, save: Optional[dict],
@@ -494,7 +513,8 @@ class Engine:
         if unpad_labels is not None and attention_mask is not None and self.unpad and B > 0:
             plan, ev = self._plan_rows(attention_mask, unpad_labels[0], unpad_labels[1], B, S, half)
         # F1 frozen backbone (no attention mask: quirk Q5; always padded - its padding positions ARE attended)
-        text_hidden = self.backbone_fwd(input_ids, S, B, half, training)
+        with self.block("K1 frozen backbone fwd"):
+            text_hidden = self.backbone_fwd(input_ids, S, B, half, training)
         self.wait_params()   # everything above read frozen weights only; from here on the trainable ones
         T, rows, cu, mask = cap, cap, None, attention_mask
         if plan is not None:
@@ -523,7 +543,8 @@ class Engine:
         # F3 encoder
         span = self._span_begin()
         for i in range(cfg.num_hidden_layers):
-            x = self.layer_fwd(P, f"bert.encoder.layer.{i}", x, B, S, mask, p_hid, p_att, i, save, T=T, cu=cu)
+            with self.block(f"K4-K8 encoder layer {i} fwd"):
+                x = self.layer_fwd(P, f"bert.encoder.layer.{i}", x, B, S, mask, p_hid, p_att, i, save, T=T, cu=cu)
         self._span_end("encoder_fwd", span)
         seq_out = x
         # F4 pooler (fp32 master weights) on position 0 of every sequence
@@ -753,8 +774,9 @@ class Engine:
         span = self._span_begin()
         for i in reversed(range(cfg.num_hidden_layers)):
             prefix = f"bert.encoder.layer.{i}"
-            dy = self.layer_bwd(prefix, dy, B, S, sv["attention_mask"], sv["p_hid"], sv["p_att"], i, sv[prefix], T=T, cu=cu,
-                                rows=rows)
+            with self.block(f"K15 encoder layer {i} bwd"):
+                dy = self.layer_bwd(prefix, dy, B, S, sv["attention_mask"], sv["p_hid"], sv["p_att"], i, sv[prefix], T=T,
+                                    cu=cu, rows=rows)
             notify(prefix)
         if span is not None and self._wstream is not None:   # (timing only) the span ends when the layers' weight gradients have
             torch.cuda.current_stream().wait_stream(self._wstream)

@@ -250,14 +250,20 @@ class STonKGsForPreTraining(nn.Module):
 
     # -------------------------------------------------------------- masters <-> derived copies
     # The GEMMs read bf16 mirrors and bf16 W^T copies of the fp32 master weights; the fused optimizer refreshes them itself.
-    # Anything ELSE that writes the masters (a torch optimizer stepping the nn.Parameters after loss.backward(), a manual
-    # `p.data.copy_`, `load_state_dict`) is noticed here: in-place writes through the parameters bump the version counter
-    # their flat buffer shares with them, and an autograd-driven backward sets `_external_step_pending` (covers writers
-    # that go through `.data`, which has a version counter of its own).
-    def _mark_synced(self) -> None:
+    # Anything ELSE that writes the masters is noticed here as far as torch lets it be noticed:
+    #  * in-place writes THROUGH the parameters (a torch optimizer's step, `p.copy_` / `p.add_` under no_grad,
+    #    `load_state_dict`) bump the version counter the parameter views share with their flat buffer;
+    #  * an autograd-driven backward sets `_external_step_pending`: whoever called loss.backward() is about to step the
+    #    masters, possibly through `p.data` - which has a version counter of its OWN and is invisible above. The flag stays
+    #    set until a version change is seen (the ordinary optimizer) or `refresh()` is called: while it is set, every forward
+    #    re-derives the copies (0.5 ms), so a `.data`-writing optimizer is never read stale;
+    #  * a write through `p.data` that no backward preceded (weight surgery before eval / encode) CANNOT be seen:
+    #    call `model.refresh()` after it.
+    def _mark_synced(self, clear_pending: bool = True) -> None:
         self._synced_versions = (self._store.data._version, self._bb_store.data._version,
                                  self._heads_store.data._version)
-        self._external_step_pending = False
+        if clear_pending:
+            self._external_step_pending = False
 
     def _sync_derived(self) -> None:
         """Called at the top of every forward: bring the bf16 mirrors / W^T copies (and, if the frozen backbone was
@@ -266,11 +272,12 @@ class STonKGsForPreTraining(nn.Module):
         if v == self._synced_versions and not self._external_step_pending:
             return
         self._wait_params()
+        changed = v != self._synced_versions
         if v[1] != self._synced_versions[1]:
             self.refresh()              # backbone changed: special vectors of the entity table too (quirk Q2)
         else:
             self.engine.refresh_derived(bf16_mirror=True)
-            self._mark_synced()
+            self._mark_synced(clear_pending=changed)   # (no version change yet: the external step may still come via .data)
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         """nn.Module.zero_grad on the flat gradient buffer: the engine's backward ACCUMULATES into it (+= / atomics), so

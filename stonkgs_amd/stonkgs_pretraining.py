@@ -336,10 +336,11 @@ class Trainer:
         self._micro += 1
         last = self._micro % gas == 0
         hook = self.sync.on_segment_done if last else None
-        loss = model.forward_backward(inputs, gscale=1.0 / gas, on_segment_done=hook)
+        with model.engine.block("K1-K15 forward + backward"):
+            loss = model.forward_backward(inputs, gscale=1.0 / gas, on_segment_done=hook)
         if last:
             lr = linear_schedule_lr(self.args.learning_rate, self.global_step, self.args.max_steps, self.args.warmup_steps)
-            with model.engine.optimizer_stream(self.args.optimizer_overlap):
+            with model.engine.optimizer_stream(self.args.optimizer_overlap), model.engine.block("K16-K17 all-reduce wait + AdamW"):
                 scale = self.sync.finish()
                 opt = self.optimizer
                 opt.step_count += 1

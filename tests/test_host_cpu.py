@@ -312,3 +312,29 @@ def test_unpad_plan_restatement_keeps_exactly_what_the_loss_reads():
     total = int(cu[-1])
     assert (rop[por[:total]] == np.arange(total)).all() and (por[total:] == -1).all()
     assert rm[cu[2]] == 0 and rop[2 * S] == cu[2]
+
+
+def test_asan_host_build_of_the_launchers():
+    """`make asan`: the launchers' HOST code (argument validation, launch geometry, descriptor handling) under
+    AddressSanitizer - the device code is built as usual and nothing is launched (no GPU here; GPU ASAN is not available on
+    this pool). The argument-validation and symbol tests above run again in a child process against that build, with the
+    sanitizer runtime preloaded; any host-side out-of-bounds access or use-after-free in a launcher aborts the child."""
+    import shutil
+    import subprocess
+    import sys
+
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    r = subprocess.run(["make", "-C", ROOT, "asan", "-j8"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lib = os.path.join(ROOT, "build", "asan", "libstonk_hip_asan.so")
+    rt = subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "-print-file-name=libclang_rt.asan-x86_64.so"],
+                        capture_output=True, text=True).stdout.strip()
+    if not os.path.exists(rt):
+        pytest.skip("no sanitizer runtime")
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", STONK_HIP_LIB=lib)
+    child = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_host_cpu.py"), "-q", "-x", "-k",
+                            "exports_every or rejected", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                           timeout=600)
+    assert child.returncode == 0 and "2 passed" in child.stdout, child.stdout[-2000:] + child.stderr[-2000:]
+    assert "AddressSanitizer" not in child.stderr

@@ -107,12 +107,16 @@ int stonk_embed_grad(const void* dx, const int64_t* token_type_ids, float* dpos,
  * (s < half), ent_labels[b,s-half] != -100 (labels nullable); a sequence WITHOUT any unmasked key keeps all S positions
  * (the reference then attends uniformly over them). Outputs (int32 unless stated, device): row_of_pos [B*S] (-1 =
  * dropped), pos_of_row [B*S] (-1 past the total), seq_offsets [B+1] ([B] = total; the `seq_offsets` of
- * stonk_attention_*), row_mask int64 [B*S] (attention_mask per packed row, 0 past the total). workspace: device ints,
- * stonk_unpad_workspace_ints(B) of them. */
+ * stonk_attention_*), row_mask int64 [B*S] (attention_mask per packed row, 0 past the total).
+ * Optionally (all three or none) the READ rows - the packed rows whose last-layer output something reads (labelled
+ * positions: the decoders; position 0: the pooler), on which alone the last layer's row-wise feed-forward block, the pooler
+ * and the head transform need to run: read_rows [B*S] (packed row of the j-th read row, -1 past their count),
+ * read_of_pos [B*S] (index into read_rows of a padded position, or -1), read_offsets [B+1] ([B] = their count;
+ * read_rows[read_offsets[b]] is position 0 of sequence b). workspace: device ints, stonk_unpad_workspace_ints(B) of them. */
 int64_t stonk_unpad_workspace_ints(int B);
 int stonk_unpad_plan(const int64_t* attention_mask, const int64_t* text_labels, const int64_t* ent_labels, int B, int S,
-                     int half, int* row_of_pos, int* pos_of_row, int* seq_offsets, int64_t* row_mask, int* workspace,
-                     int64_t ws_ints, void* stream);
+                     int half, int* row_of_pos, int* pos_of_row, int* seq_offsets, int64_t* row_mask, int* read_rows,
+                     int* read_of_pos, int* read_offsets, int* workspace, int64_t ws_ints, void* stream);
 
 /* Fused attention, head_dim 64, S % 128 == 0, S <= 4096: out = dropout(softmax(q k^T * scale + mask)) v.
  * q/k/v: column slices of the [T, 3H] projection (row stride ld), head h at columns h*64..; attention_mask int64

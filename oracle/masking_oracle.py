@@ -91,14 +91,16 @@ def assemble_rows(text_ids, text_attention, source, target, walks, sep_id=102, n
     return ids, att, typ, nsp
 
 
-def unpad_plan(attention_mask, text_labels=None, ent_labels=None):
+def unpad_plan(attention_mask, text_labels=None, ent_labels=None, read=False):
     """numpy restatement of stonkgs_amd/csrc/unpad.hip (stonk_unpad_plan): which padded positions the trainable encoder
     keeps, in position order. Kept: attention_mask != 0, position 0 (the pooler's input, hf:modeling_bert.py:457-463),
     a labelled position of either half (the reference labels 15 % of the PADDED half,
     ref:src/stonkgs/data/indra_for_pretraining.py:33-77, and nn.CrossEntropyLoss reads those rows,
     ref:src/stonkgs/models/stonkgs_model.py:229-240); a sequence without any unmasked key keeps everything (the reference
     then attends uniformly over all S keys, hf:modeling_bert.py:111-136 with every score at finfo.min).
-    Returns row_of_pos [B*S], pos_of_row [B*S], seq_offsets [B+1], row_mask [B*S]."""
+    Returns row_of_pos [B*S], pos_of_row [B*S], seq_offsets [B+1], row_mask [B*S]; with `read=True` also the READ rows
+    (labelled positions and position 0 - the only rows whose last-layer output the heads read): read_rows [B*S],
+    read_of_pos [B*S], read_offsets [B+1]."""
     am = np.asarray(attention_mask, dtype=np.int64)
     B, S = am.shape
     half = S // 2
@@ -118,4 +120,19 @@ def unpad_plan(attention_mask, text_labels=None, ent_labels=None):
     seq_offsets = np.concatenate([[0], np.cumsum(keep.sum(axis=1))]).astype(np.int32)
     row_mask = np.zeros(B * S, dtype=np.int64)
     row_mask[:total] = am.reshape(-1)[flat]
-    return row_of_pos, pos_of_row, seq_offsets, row_mask
+    if not read:
+        return row_of_pos, pos_of_row, seq_offsets, row_mask
+    rd = np.zeros((B, S), dtype=bool)
+    rd[:, 0] = True
+    if text_labels is not None:
+        rd[:, :half] |= np.asarray(text_labels) != -100
+    if ent_labels is not None:
+        rd[:, half:] |= np.asarray(ent_labels) != -100
+    rflat = rd.reshape(-1)
+    n_rd = int(rflat.sum())
+    read_rows = np.full(B * S, -1, dtype=np.int32)
+    read_rows[:n_rd] = row_of_pos[rflat]
+    read_of_pos = np.full(B * S, -1, dtype=np.int32)
+    read_of_pos[rflat] = np.arange(n_rd, dtype=np.int32)
+    read_offsets = np.concatenate([[0], np.cumsum(rd.sum(axis=1))]).astype(np.int32)
+    return row_of_pos, pos_of_row, seq_offsets, row_mask, read_rows, read_of_pos, read_offsets

@@ -43,7 +43,7 @@ _SIGNATURES = {
                             _vp, _i64, _vp],
     "stonk_joint_embed_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                  _i64, _i32, _f32, _i32, _f32, _u32, _vp, _vp, _i64, _vp],
-    "stonk_unpad_plan": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "stonk_unpad_plan": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "stonk_text_embed_ln_fwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _f32, _i32, _f32,
                                 _u32, _vp, _vp],
     "stonk_embed_grad": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],

@@ -13,6 +13,12 @@
 //   pos_of_row [B*S]  padded position of packed row i (i < total), -1 beyond
 //   seq_offsets[B+1]  first packed row of every sequence; [B] = total (what stonk_attention_* take as `seq_offsets`)
 //   row_mask  [B*S]   attention_mask gathered to packed rows (int64, 0 beyond total)
+// and, optionally, the READ rows - packed rows whose LAST-layer output something reads: labelled positions (the decoders)
+// and position 0 (the pooler). The last encoder layer's feed-forward block, the pooler and the head transform are
+// row-wise, so they only need to run on those (about 77 of a sequence's ~410 rows):
+//   read_rows  [B*S]  packed row of the j-th read row (position order), -1 beyond their count
+//   read_of_pos[B*S]  index into read_rows of padded position b*S+s, or -1
+//   read_offsets[B+1] first read row of every sequence ([B] = their count); read_rows[read_offsets[b]] is position 0 of b
 // A sequence WITHOUT any live key keeps all of its positions (the reference then attends uniformly over all S keys).
 // Integer work, bit-exact by construction; tests compare with a numpy restatement (oracle/masking_oracle.py).
 #include "common.h"
@@ -21,6 +27,12 @@
 namespace {
 
 constexpr int TPB = 256;
+
+__device__ __forceinline__ bool read_position(const long* text_labels, const long* ent_labels, int b, int s, int half) {
+  if (s == 0) return true;
+  if (s < half) return text_labels && text_labels[(long)b * half + s] != -100;
+  return ent_labels && s - half < half && ent_labels[(long)b * half + (s - half)] != -100;
+}
 
 __device__ __forceinline__ bool keep_position(const long* mask, const long* text_labels, const long* ent_labels, int b,
                                               int s, int S, int half, bool any_live) {
@@ -56,7 +68,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total) {
 // pass 1, one workgroup per sequence: how many positions it keeps
 __global__ __launch_bounds__(TPB) void unpad_count_kernel(const long* __restrict__ mask,
                                                           const long* __restrict__ text_labels,
-                                                          const long* __restrict__ ent_labels, int S, int half,
+                                                          const long* __restrict__ ent_labels, int B, int S, int half,
                                                           int* __restrict__ counts, int* __restrict__ live_flags) {
   const int b = blockIdx.x;
   __shared__ int any_live_s;
@@ -67,13 +79,18 @@ __global__ __launch_bounds__(TPB) void unpad_count_kernel(const long* __restrict
   if (__ballot(live) != 0 && (threadIdx.x & 63) == 0) atomicOr(&any_live_s, 1);
   __syncthreads();
   const bool any_live = any_live_s != 0;
-  int cnt = 0;
-  for (int s = threadIdx.x; s < S; s += TPB) cnt += keep_position(mask, text_labels, ent_labels, b, s, S, half, any_live);
-  int total;
+  int cnt = 0, rd = 0;
+  for (int s = threadIdx.x; s < S; s += TPB) {
+    cnt += keep_position(mask, text_labels, ent_labels, b, s, S, half, any_live);
+    rd += read_position(text_labels, ent_labels, b, s, half);
+  }
+  int total, total_rd;
   block_excl_scan(cnt, &total);
+  block_excl_scan(rd, &total_rd);
   if (threadIdx.x == 0) {
     counts[b] = total;
     live_flags[b] = any_live;
+    counts[2 * B + b] = total_rd;   // (workspace: [0,B) kept, [B,2B) live flags, [2B,3B) read rows)
   }
 }
 
@@ -83,56 +100,82 @@ __global__ __launch_bounds__(TPB) void unpad_fill_kernel(const long* __restrict_
                                                          const long* __restrict__ ent_labels, int B, int S, int half,
                                                          const int* __restrict__ counts, const int* __restrict__ live_flags,
                                                          int* __restrict__ row_of_pos, int* __restrict__ pos_of_row,
-                                                         int* __restrict__ seq_offsets, long* __restrict__ row_mask) {
+                                                         int* __restrict__ seq_offsets, long* __restrict__ row_mask,
+                                                         int* __restrict__ read_rows, int* __restrict__ read_of_pos,
+                                                         int* __restrict__ read_offsets) {
   const int b = blockIdx.x;
-  int before = 0, all = 0;
+  int before = 0, all = 0, rbefore = 0, rall = 0;
   for (int j = threadIdx.x; j < B; j += TPB) {
-    const int c = counts[j];
+    const int c = counts[j], rc = counts[2 * B + j];
     all += c;
-    if (j < b) before += c;
+    rall += rc;
+    if (j < b) {
+      before += c;
+      rbefore += rc;
+    }
   }
-  __shared__ int red[2][TPB / 64];
+  __shared__ int red[4][TPB / 64];
   {
-    int x = before, y = all;
+    int x = before, y = all, z = rbefore, w = rall;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       x += __shfl_xor(x, o, 64);
       y += __shfl_xor(y, o, 64);
+      z += __shfl_xor(z, o, 64);
+      w += __shfl_xor(w, o, 64);
     }
     if ((threadIdx.x & 63) == 0) {
       red[0][threadIdx.x >> 6] = x;
       red[1][threadIdx.x >> 6] = y;
+      red[2][threadIdx.x >> 6] = z;
+      red[3][threadIdx.x >> 6] = w;
     }
     __syncthreads();
-    before = all = 0;
+    before = all = rbefore = rall = 0;
 #pragma unroll
     for (int j = 0; j < TPB / 64; ++j) {
       before += red[0][j];
       all += red[1][j];
+      rbefore += red[2][j];
+      rall += red[3][j];
     }
     __syncthreads();
   }
   const bool any_live = live_flags[b] != 0;
   const int per = (S + TPB - 1) / TPB;
   const int s0 = threadIdx.x * per, s1 = s0 + per < S ? s0 + per : S;
-  int cnt = 0;
-  for (int s = s0; s < s1; ++s) cnt += keep_position(mask, text_labels, ent_labels, b, s, S, half, any_live);
+  int cnt = 0, rd = 0;
+  for (int s = s0; s < s1; ++s) {
+    cnt += keep_position(mask, text_labels, ent_labels, b, s, S, half, any_live);
+    rd += read_position(text_labels, ent_labels, b, s, half);
+  }
   int total;
   int row = before + block_excl_scan(cnt, &total);
+  int rrow = rbefore + block_excl_scan(rd, &total);
   for (int s = s0; s < s1; ++s) {
     const long p = (long)b * S + s;
-    if (keep_position(mask, text_labels, ent_labels, b, s, S, half, any_live)) {
+    const bool kept = keep_position(mask, text_labels, ent_labels, b, s, S, half, any_live);
+    if (kept) {
       row_of_pos[p] = row;
       pos_of_row[row] = (int)p;
       row_mask[row] = mask[p];
-      ++row;
     } else {
       row_of_pos[p] = -1;
     }
+    if (read_rows) {   // (a read position is always a kept one)
+      const bool rdp = read_position(text_labels, ent_labels, b, s, half);
+      read_of_pos[p] = rdp ? rrow : -1;
+      if (rdp) read_rows[rrow++] = row;
+    }
+    row += kept;
   }
   if (threadIdx.x == 0) {
     seq_offsets[b] = before;
     if (b == B - 1) seq_offsets[B] = all;
+    if (read_rows) {
+      read_offsets[b] = rbefore;
+      if (b == B - 1) read_offsets[B] = rall;
+    }
   }
   // rows past the total belong to no position
   const long cap = (long)B * S;
@@ -140,24 +183,28 @@ __global__ __launch_bounds__(TPB) void unpad_fill_kernel(const long* __restrict_
     pos_of_row[i] = -1;
     row_mask[i] = 0;
   }
+  if (read_rows)
+    for (long i = rall + (long)b * TPB + threadIdx.x; i < cap; i += (long)B * TPB) read_rows[i] = -1;
 }
 
 }  // namespace
 
-extern "C" int64_t stonk_unpad_workspace_ints(int B) { return B > 0 ? 2L * B : 0; }
+extern "C" int64_t stonk_unpad_workspace_ints(int B) { return B > 0 ? 3L * B : 0; }
 
 extern "C" int stonk_unpad_plan(const int64_t* attention_mask, const int64_t* text_labels, const int64_t* ent_labels, int B,
                                 int S, int half, int* row_of_pos, int* pos_of_row, int* seq_offsets, int64_t* row_mask,
-                                int* workspace, int64_t ws_ints, void* stream) {
+                                int* read_rows, int* read_of_pos, int* read_offsets, int* workspace, int64_t ws_ints,
+                                void* stream) {
   STONK_CHECK_ARG(attention_mask && row_of_pos && pos_of_row && seq_offsets && row_mask && workspace, STONK_EINVAL);
+  STONK_CHECK_ARG((read_rows && read_of_pos && read_offsets) || (!read_rows && !read_of_pos && !read_offsets), STONK_EINVAL);
   STONK_CHECK_ARG(B >= 0 && S > 0 && half >= 0 && half <= S && (long)B * S < (1L << 31), STONK_ESHAPE);
-  STONK_CHECK_ARG(ws_ints >= 2L * B, STONK_EINVAL);
+  STONK_CHECK_ARG(ws_ints >= 3L * B, STONK_EINVAL);
   if (B == 0) return STONK_OK;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(unpad_count_kernel, dim3(B), dim3(TPB), 0, st, (const long*)attention_mask, (const long*)text_labels,
-                     (const long*)ent_labels, S, half, workspace, workspace + B);
+                     (const long*)ent_labels, B, S, half, workspace, workspace + B);
   hipLaunchKernelGGL(unpad_fill_kernel, dim3(B), dim3(TPB), 0, st, (const long*)attention_mask, (const long*)text_labels,
                      (const long*)ent_labels, B, S, half, workspace, workspace + B, row_of_pos, pos_of_row, seq_offsets,
-                     (long*)row_mask);
+                     (long*)row_mask, read_rows, read_of_pos, read_offsets);
   return stonk_launch_status();
 }

@@ -102,9 +102,13 @@ class Engine:
         # nor dense logits (`forward_backward`, `forward(..., return_dict=False)` in training mode); costs one host wait
         # per step for the packed row count, taken while the frozen backbone's forward is already queued.
         self.unpad = True
+        # ... and, in the packed layout, the LAST layer's feed-forward block, the pooler and the head transform run on the
+        # READ rows only (labelled positions + position 0: ~77 of a sequence's ~410 rows) - they are row-wise, and nothing
+        # reads the last layer's output at any other row. Attention and its projections still see every row (keys).
+        self.prune_last_ffn = True
         # what ran: [rows, padded rows they stand for, encoder passes, sum over sequences of rows^2, of S^2] - bench.py prices
         # the step on the FLOPs actually executed (linear layers ~ rows, attention ~ rows^2 per sequence)
-        self.rows_executed = [0, 0, 0, 0, 0]
+        self.rows_executed = [0, 0, 0, 0, 0, 0]   # (last: rows of the last layer's feed-forward block / pooler / head)
         self._plan_host: Optional[torch.Tensor] = None
         self._wstream: Optional[torch.cuda.Stream] = None
         # The optimizer (grad-norm, AdamW, W^T refresh: ~2 ms of HBM-bound work) runs on a third stream; the next step's
@@ -314,9 +318,11 @@ class Engine:
 
     # ------------------------------------------------------------------ one BERT layer
     def layer_fwd(self, S: FlatStore, prefix: str, x, B, seq, mask, p_hid, p_att, lidx, save: Optional[dict],
-                  T: Optional[int] = None, cu=None):
+                  T: Optional[int] = None, cu=None, rd: Optional[dict] = None):
         """One BERT layer on T rows. Padded layout: T = B * seq, `mask` = attention_mask [B, seq]. Packed layout (`cu` =
-        sequence offsets of stonk_unpad_plan): T = the packed row count rounded up to 64, `mask` = one word per row."""
+        sequence offsets of stonk_unpad_plan): T = the packed row count rounded up to 64, `mask` = one word per row.
+        `rd` (last layer of the packed layout): the feed-forward block runs on the READ rows only - gathered after the
+        attention block's LayerNorm - and the layer's output has rd["T"] rows."""
         cfg = self.cfg
         H, I, NH = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
         cap = B * seq
@@ -345,28 +351,34 @@ class Engine:
         hip.call("stonk_layernorm_fwd", s1.data_ptr(), f(prefix + ".attention.output.LayerNorm.weight").data_ptr(),
                  f(prefix + ".attention.output.LayerNorm.bias").data_ptr(), h1.data_ptr(), st1[0].data_ptr(),
                  st1[1].data_ptr(), T, H, cfg.layer_norm_eps, 0, 0.0, 0, st)
+        hf, Tf = h1, T                             # input rows of the feed-forward block
+        if rd is not None:
+            hf, Tf = self.buf(f"{tag}.h1rd", (cap, H)), rd["T"]
+            hip.call("stonk_gather_rows_bf16", h1.data_ptr(), H, rd["rows"].data_ptr(), rd["cnt"].data_ptr(), hf.data_ptr(),
+                     H, H, cap, st)            # (rows from the count up to the next multiple of 128 are zero-filled)
         g = self.buf(f"{tag}.g", (cap, I))
         u = self.buf(f"{tag}.u", (cap, I)) if save is not None else None
         fl = hip.EPI_BIAS | hip.EPI_GELU | ((hip.EPI_SAVE_PREACT | hip.EPI_AUX_GRAD) if save is not None else 0)
-        self.gemm(h1, w(prefix + ".intermediate.dense.weight"), g, T, I, H, flags=fl,
+        self.gemm(hf, w(prefix + ".intermediate.dense.weight"), g, Tf, I, H, flags=fl,
                   bias=f(prefix + ".intermediate.dense.bias"), aux=u, kernel=self._kernel("ffn_up"))
         s2 = self.buf(f"{tag}.s2", (cap, H))
         fl = hip.EPI_BIAS | hip.EPI_RESID | (hip.EPI_DROPOUT if p_hid > 0 else 0)
-        self.gemm(g, w(prefix + ".output.dense.weight"), s2, T, H, I, flags=fl, bias=f(prefix + ".output.dense.bias"),
-                  resid=h1, drop_p=p_hid, seed=self.seed(lidx, 3), kernel=self._kernel("ffn_down"))
+        self.gemm(g, w(prefix + ".output.dense.weight"), s2, Tf, H, I, flags=fl, bias=f(prefix + ".output.dense.bias"),
+                  resid=hf, drop_p=p_hid, seed=self.seed(lidx, 3), kernel=self._kernel("ffn_down"))
         y = self.buf(f"{prefix}.y" if save is not None else f"tmp.y{lidx & 1}", (cap, H))
         st2 = self.buf(f"{tag}.st2", (2, cap), F32)
         hip.call("stonk_layernorm_fwd", s2.data_ptr(), f(prefix + ".output.LayerNorm.weight").data_ptr(),
-                 f(prefix + ".output.LayerNorm.bias").data_ptr(), y.data_ptr(), st2[0].data_ptr(), st2[1].data_ptr(), T,
+                 f(prefix + ".output.LayerNorm.bias").data_ptr(), y.data_ptr(), st2[0].data_ptr(), st2[1].data_ptr(), Tf,
                  H, cfg.layer_norm_eps, 0, 0.0, 0, st)
         if save is not None:
-            save[prefix] = dict(x=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, h1=h1, st1=st1, g=g, u=u, s2=s2, st2=st2)
+            save[prefix] = dict(x=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, h1=hf, st1=st1, g=g, u=u, s2=s2, st2=st2)
         return y
 
     def layer_bwd(self, prefix: str, dy, B, seq, mask, p_hid, p_att, lidx, sv, T: Optional[int] = None, cu=None,
-                  rows: Optional[int] = None):
+                  rows: Optional[int] = None, rd: Optional[dict] = None):
         """dy: bf16 [T,H] gradient of the layer output. Returns the gradient of the layer input. Packed layout: `cu`,
-        per-row `mask`, T = packed rows rounded up to 64, `rows` = the packed rows that belong to a sequence."""
+        per-row `mask`, T = packed rows rounded up to 64, `rows` = the packed rows that belong to a sequence. `rd`: the
+        feed-forward block ran on the read rows (dy has rd["T"] rows); its input gradient is scattered back to all rows."""
         cfg = self.cfg
         H, I, NH = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
         cap = B * seq
@@ -385,23 +397,32 @@ class Engine:
         # ---- LN2 backward: ds2 (residual branch) and df (through the FFN-output dropout)
         ds2 = self.buf(f"b.ds2.{par}", (cap, H))
         df = self.buf(f"b.df.{par}", (cap, H)) if p_hid > 0 else None
+        Tf = T if rd is None else rd["T"]          # rows the feed-forward block ran on
         hip.call("stonk_layernorm_bwd", dy.data_ptr(), sv["s2"].data_ptr(), sv["st2"][0].data_ptr(),
                  sv["st2"][1].data_ptr(), f(prefix + ".output.LayerNorm.weight").data_ptr(), ds2.data_ptr(), hip.ptr(df),
                  g_(prefix + ".output.LayerNorm.weight").data_ptr(), g_(prefix + ".output.LayerNorm.bias").data_ptr(),
-                 T, H, 0, 0.0, 0, p_hid, self.seed(lidx, 3), self.ln_ws().data_ptr(), self.ln_ws().numel(), st)
+                 Tf, H, 0, 0.0, 0, p_hid, self.seed(lidx, 3), self.ln_ws().data_ptr(), self.ln_ws().numel(), st)
         if df is None:
             df = ds2
         # ---- FFN down: wgrad, bias grad, dgrad fused with GELU'
-        self.wgrad(df, sv["g"], g_(prefix + ".output.dense.weight"), g_(prefix + ".output.dense.bias"), H, I, T)
+        self.wgrad(df, sv["g"], g_(prefix + ".output.dense.weight"), g_(prefix + ".output.dense.bias"), H, I, Tf)
         du = self.buf(f"b.du.{par}", (cap, I))
-        self.gemm(df, wt[prefix + ".output.dense.weight"], du, T, I, H, flags=hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD,
+        self.gemm(df, wt[prefix + ".output.dense.weight"], du, Tf, I, H, flags=hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD,
                   aux=sv["u"], kernel=self._kernel("dgrad_gelu", True))
         # ---- FFN up
         self.wgrad(du, sv["h1"], g_(prefix + ".intermediate.dense.weight"), g_(prefix + ".intermediate.dense.bias"), I, H,
-                   T)
+                   Tf)
         dh1 = self.buf("b.dh1", (cap, H))
-        self.gemm(du, wt[prefix + ".intermediate.dense.weight"], dh1, T, H, I, flags=hip.EPI_RESID, resid=ds2,
-                  kernel=self._kernel("dgrad_resid", True))
+        if rd is None:
+            self.gemm(du, wt[prefix + ".intermediate.dense.weight"], dh1, T, H, I, flags=hip.EPI_RESID, resid=ds2,
+                      kernel=self._kernel("dgrad_resid", True))
+        else:   # gradient of the gathered rows, scattered into an otherwise zero gradient of the attention block's output
+            dh1rd = self.buf("b.dh1rd", (cap, H))
+            self.gemm(du, wt[prefix + ".intermediate.dense.weight"], dh1rd, Tf, H, I, flags=hip.EPI_RESID, resid=ds2,
+                      kernel=self._kernel("dgrad_resid", True))
+            dh1[:T].zero_()
+            hip.call("stonk_scatter_rows_bf16", dh1rd.data_ptr(), H, rd["rows"].data_ptr(), rd["cnt"].data_ptr(),
+                     dh1.data_ptr(), H, H, st)
         # ---- LN1 backward
         ds1 = self.buf(f"b.ds1.{par}", (cap, H))
         da = self.buf(f"b.da.{par}", (cap, H)) if p_hid > 0 else None
@@ -483,16 +504,21 @@ class Engine:
         pos_of_row = self.buf("u.pos_of_row", (n,), I32)
         cu = self.buf("u.cu", (B + 1,), I32)
         row_mask = self.buf("u.row_mask", (n,), torch.int64)
+        offs = self.buf("u.offsets", (2 * (B + 1),), I32)        # [sequence offsets | read-row offsets]: one copy to the host
+        cu, cu_rd = offs[:B + 1], offs[B + 1:]
+        read_rows = self.buf("u.read_rows", (n,), I32)
+        read_of_pos = self.buf("u.read_of_pos", (n,), I32)
         ws = self.buf("u.ws", (int(hip.lib().stonk_unpad_workspace_ints(B)),), I32)
         hip.call("stonk_unpad_plan", attention_mask.data_ptr(), hip.ptr(mlm_labels), hip.ptr(ent_labels), B, S, half,
-                 row_of_pos.data_ptr(), pos_of_row.data_ptr(), cu.data_ptr(), row_mask.data_ptr(), ws.data_ptr(),
-                 ws.numel(), hip.stream_ptr())
-        if self._plan_host is None or self._plan_host.numel() < B + 1:
-            self._plan_host = torch.empty(B + 1, dtype=I32).pin_memory()
-        self._plan_host[:B + 1].copy_(cu, non_blocking=True)
+                 row_of_pos.data_ptr(), pos_of_row.data_ptr(), cu.data_ptr(), row_mask.data_ptr(), read_rows.data_ptr(),
+                 read_of_pos.data_ptr(), cu_rd.data_ptr(), ws.data_ptr(), ws.numel(), hip.stream_ptr())
+        if self._plan_host is None or self._plan_host.numel() < 2 * (B + 1):
+            self._plan_host = torch.empty(2 * (B + 1), dtype=I32).pin_memory()
+        self._plan_host[:2 * (B + 1)].copy_(offs, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return dict(row_of_pos=row_of_pos, pos_of_row=pos_of_row, cu=cu, row_mask=row_mask), ev
+        return dict(row_of_pos=row_of_pos, pos_of_row=pos_of_row, cu=cu, row_mask=row_mask, read_rows=read_rows,
+                    read_of_pos=read_of_pos, cu_rd=cu_rd), ev
 
     def encode(self, input_ids, attention_mask, token_type_ids, training: bool, save: dict, unpad_labels=None):
         """F1-F4: frozen backbone, KG gather + embeddings LayerNorm, encoder layers, pooler. Shared by the pre-training
@@ -516,17 +542,22 @@ class Engine:
         with self.block("K1 frozen backbone fwd"):
             text_hidden = self.backbone_fwd(input_ids, S, B, half, training)
         self.wait_params()   # everything above read frozen weights only; from here on the trainable ones
-        T, rows, cu, mask = cap, cap, None, attention_mask
+        T, rows, cu, mask, rd = cap, cap, None, attention_mask, None
         if plan is not None:
             ev.synchronize()                       # (the backbone's launches are queued: the GPU is not waiting for us)
-            offs = self._plan_host[:B + 1].tolist()
+            host = self._plan_host[:2 * (B + 1)].tolist()
+            offs, n_read = host[:B + 1], host[2 * B + 1]
             rows = offs[B]
             T = min(cap, (rows + 63) // 64 * 64)   # whole 64-row K tiles for the weight gradients; the tail rows are zeros
             cu, mask = plan["cu"], plan["row_mask"]
             sq = sum((offs[i + 1] - offs[i]) ** 2 for i in range(B))
+            if self.prune_last_ffn:
+                rd = dict(rows=plan["read_rows"], cnt=plan["cu_rd"][B:B + 1], n=n_read,
+                          T=min(cap, (n_read + 63) // 64 * 64))
         else:
             sq = B * S * S
-        for i, v in enumerate((T, cap, 1, sq, B * S * S)):
+        Th = T if rd is None else rd["T"]          # rows of the sequence output (and of everything the heads run on)
+        for i, v in enumerate((T, cap, 1, sq, B * S * S, Th)):
             self.rows_executed[i] += v
         # F2 gather + concat + embeddings LayerNorm
         sum0 = self.buf("e.sum0", (cap, H))
@@ -542,27 +573,31 @@ class Engine:
                  T if plan is not None else 0, st)
         # F3 encoder
         span = self._span_begin()
+        last = cfg.num_hidden_layers - 1
         for i in range(cfg.num_hidden_layers):
             with self.block(f"K4-K8 encoder layer {i} fwd"):
-                x = self.layer_fwd(P, f"bert.encoder.layer.{i}", x, B, S, mask, p_hid, p_att, i, save, T=T, cu=cu)
+                x = self.layer_fwd(P, f"bert.encoder.layer.{i}", x, B, S, mask, p_hid, p_att, i, save, T=T, cu=cu,
+                                   rd=rd if i == last else None)
         self._span_end("encoder_fwd", span)
-        seq_out = x
+        seq_out = x                                # [Th rows]: every packed row, or the read rows only
         # F4 pooler (fp32 master weights) on position 0 of every sequence
         pooled = self.buf("h.pooled", (B, H), F32)
+        first_rows = None if plan is None else (cu if rd is None else plan["cu_rd"])
         if plan is None:
             first, ld_first = seq_out, S * H
-        else:   # packed: position 0 of sequence b is row cu[b]
+        else:   # packed: position 0 of sequence b is row cu[b] (among the read rows: read_offsets[b])
             nb = self.buf("u.nb", (1,), I32)
             nb.fill_(B)
             first, ld_first = self.buf("h.first", ((B + 127) // 128 * 128, H)), H
-            hip.call("stonk_gather_rows_bf16", seq_out.data_ptr(), H, cu.data_ptr(), nb.data_ptr(), first.data_ptr(), H, H,
-                     first.shape[0], st)
+            hip.call("stonk_gather_rows_bf16", seq_out.data_ptr(), H, first_rows.data_ptr(), nb.data_ptr(), first.data_ptr(),
+                     H, H, first.shape[0], st)
         hip.call("stonk_small_linear_fwd", first.data_ptr(), ld_first, f("bert.pooler.dense.weight").data_ptr(),
                  f("bert.pooler.dense.bias").data_ptr(), pooled.data_ptr(), B, H, H, hip.SMALL_TANH, st)
         if save is not None:   # (None: forward-only callers - embedding extraction, batched inference)
             save.update(B=B, attention_mask=mask, token_type_ids=token_type_ids, sum0=sum0, st0=st0,
                         seq_out=seq_out, pooled=pooled, p_hid=p_hid, p_att=p_att, T=T, rows=rows, plan=plan,
-                        first=first, ld_first=ld_first)
+                        first=first, ld_first=ld_first, rd=rd, Th=Th, first_rows=first_rows,
+                        head_map=None if plan is None else (plan["row_of_pos"] if rd is None else plan["read_of_pos"]))
         return seq_out, pooled
 
     def forward(self, input_ids, attention_mask, token_type_ids, mlm_labels, ent_labels, nsp_labels, training: bool,
@@ -581,8 +616,8 @@ class Engine:
         packed = have_labels and not dense_logits and not want_hidden
         seq_out, pooled = self.encode(input_ids, attention_mask, token_type_ids, training, save,
                                       (mlm_labels, ent_labels) if packed else None)
-        T, plan = save["T"], save["plan"]
-        row_of_pos = None if plan is None else plan["row_of_pos"]
+        T, plan = save["Th"], save["plan"]          # rows of the sequence output: all packed rows, or the read rows
+        row_of_pos = save["head_map"]
         nsp = self.buf("h.nsp", (B, 2), F32)
         hip.call("stonk_small_linear_fwd", pooled.data_ptr(), H, f("cls.seq_relationship.weight").data_ptr(),
                  f("cls.seq_relationship.bias").data_ptr(), nsp.data_ptr(), B, 2, H, hip.SMALL_X_F32, st)
@@ -666,7 +701,7 @@ class Engine:
         cfg = self.cfg
         H, S, half = cfg.hidden_size, cfg.max_position_embeddings, cfg.half_length
         B = sv["B"]
-        T, cap_rows = sv["T"], B * S
+        T, cap_rows = sv["Th"], B * S               # the heads ran on the sequence output's rows
         st = hip.stream_ptr()
         P = self.P
         f, g_, wt = P.view, P.grad_view, P.wt
@@ -749,34 +784,35 @@ class Engine:
         cfg = self.cfg
         H, S = cfg.hidden_size, cfg.max_position_embeddings
         B = sv["B"]
-        T, rows, plan = sv["T"], sv["rows"], sv["plan"]
+        T, rows, plan, rd, first_rows = sv["T"], sv["rows"], sv["plan"], sv["rd"], sv["first_rows"]
         cap = B * S
         st = hip.stream_ptr()
         f, g_ = self.P.view, self.P.grad_view
         if plan is None:
             acc, ld_acc = dseq, S * H
-        else:   # packed: position 0 of sequence b is row cu[b] - its gradient rows are gathered, added to, scattered back
+        else:   # packed: position 0 of sequence b is row first_rows[b] - its gradient rows are gathered, added to, scattered back
             nb = self.buf("u.nb", (1,), I32)
             nb.fill_(B)
             acc, ld_acc = self.buf("b.dfirst", ((B + 127) // 128 * 128, H)), H
-            hip.call("stonk_gather_rows_bf16", dseq.data_ptr(), H, plan["cu"].data_ptr(), nb.data_ptr(), acc.data_ptr(), H,
+            hip.call("stonk_gather_rows_bf16", dseq.data_ptr(), H, first_rows.data_ptr(), nb.data_ptr(), acc.data_ptr(), H,
                      H, acc.shape[0], st)
         hip.call("stonk_small_linear_bwd", dpooled.data_ptr(), sv["pooled"].data_ptr(), sv["first"].data_ptr(),
                  sv["ld_first"], f("bert.pooler.dense.weight").data_ptr(), g_("bert.pooler.dense.weight").data_ptr(),
                  g_("bert.pooler.dense.bias").data_ptr(), 0, acc.data_ptr(), ld_acc, B, H, H, hip.SMALL_TANH, st)
         if plan is not None:
-            hip.call("stonk_scatter_rows_bf16", acc.data_ptr(), H, plan["cu"].data_ptr(), nb.data_ptr(), dseq.data_ptr(), H,
+            hip.call("stonk_scatter_rows_bf16", acc.data_ptr(), H, first_rows.data_ptr(), nb.data_ptr(), dseq.data_ptr(), H,
                      H, st)
         notify("bert.pooler.dense.bias")
         # ---- encoder layers, last to first
         dy = dseq
         cu = None if plan is None else plan["cu"]
+        last = cfg.num_hidden_layers - 1
         span = self._span_begin()
         for i in reversed(range(cfg.num_hidden_layers)):
             prefix = f"bert.encoder.layer.{i}"
             with self.block(f"K15 encoder layer {i} bwd"):
                 dy = self.layer_bwd(prefix, dy, B, S, sv["attention_mask"], sv["p_hid"], sv["p_att"], i, sv[prefix], T=T,
-                                    cu=cu, rows=rows)
+                                    cu=cu, rows=rows, rd=rd if i == last else None)
             notify(prefix)
         if span is not None and self._wstream is not None:   # (timing only) the span ends when the layers' weight gradients have
             torch.cuda.current_stream().wait_stream(self._wstream)
@@ -861,5 +897,5 @@ class Engine:
             hip.call("stonk_dropout_f32", dpooled.data_ptr(), dpooled.data_ptr(), B * H, sv["p_cls"], self.seed(300, 0), st)
         notify("classifier.bias")
         dseq = self.buf("b.dseq", (B * S, H))
-        dseq[:sv["T"]].zero_()  # only position 0 of every sequence receives a gradient (from the pooler)
+        dseq[:sv["Th"]].zero_()  # only position 0 of every sequence receives a gradient (from the pooler)
         self.backward_encoder(dpooled, dseq, sv, notify)

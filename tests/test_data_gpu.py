@@ -133,11 +133,28 @@ def test_unpad_plan_equals_numpy_restatement(hip, B, S):
         cu = torch.full((B + 1,), -7, dtype=torch.int32, device="cuda")
         rm = torch.full((B * S,), -7, dtype=torch.int64, device="cuda")
         ws = torch.zeros(int(hip.lib().stonk_unpad_workspace_ints(B)), dtype=torch.int32, device="cuda")
+        rr = torch.full((B * S,), -7, dtype=torch.int32, device="cuda")
+        rofp = torch.full((B * S,), -7, dtype=torch.int32, device="cuda")
+        ro = torch.full((B + 1,), -7, dtype=torch.int32, device="cuda")
         hip.call("stonk_unpad_plan", hip.ptr(d_am), hip.ptr(d_tl) if use_labels else 0, hip.ptr(d_el) if use_labels else 0,
-                 B, S, half, hip.ptr(rop), hip.ptr(por), hip.ptr(cu), hip.ptr(rm), hip.ptr(ws), ws.numel(), hip.stream_ptr())
-        e_rop, e_por, e_cu, e_rm = mo.unpad_plan(am, tl if use_labels else None, el if use_labels else None)
+                 B, S, half, hip.ptr(rop), hip.ptr(por), hip.ptr(cu), hip.ptr(rm), hip.ptr(rr), hip.ptr(rofp), hip.ptr(ro),
+                 hip.ptr(ws), ws.numel(), hip.stream_ptr())
+        e_rop, e_por, e_cu, e_rm, e_rr, e_rofp, e_ro = mo.unpad_plan(am, tl if use_labels else None,
+                                                                     el if use_labels else None, read=True)
         assert np.array_equal(cu.cpu().numpy(), e_cu)
         assert np.array_equal(rop.cpu().numpy(), e_rop) and np.array_equal(por.cpu().numpy(), e_por)
         assert np.array_equal(rm.cpu().numpy(), e_rm)
+        assert np.array_equal(ro.cpu().numpy(), e_ro) and np.array_equal(rr.cpu().numpy(), e_rr)
+        assert np.array_equal(rofp.cpu().numpy(), e_rofp)
+        n_rd = int(e_ro[-1])
+        assert (e_por[e_rr[e_ro[:-1]]] % S == 0).all() and n_rd >= B      # every sequence's first read row is its position 0
+        # the three read outputs are optional as a group
+        rop2 = torch.empty_like(rop)
+        hip.call("stonk_unpad_plan", hip.ptr(d_am), hip.ptr(d_tl) if use_labels else 0, hip.ptr(d_el) if use_labels else 0,
+                 B, S, half, hip.ptr(rop2), hip.ptr(por), hip.ptr(cu), hip.ptr(rm), 0, 0, 0, hip.ptr(ws), ws.numel(),
+                 hip.stream_ptr())
+        assert torch.equal(rop2, rop)
+        assert hip.lib().stonk_unpad_plan(hip.ptr(d_am), 0, 0, B, S, half, hip.ptr(rop2), hip.ptr(por), hip.ptr(cu),
+                                          hip.ptr(rm), hip.ptr(rr), 0, 0, hip.ptr(ws), ws.numel(), hip.stream_ptr()) == -1
         total = int(e_cu[-1])
         assert 0 < total <= B * S and (use_labels is False or total >= int((am != 0).sum()))

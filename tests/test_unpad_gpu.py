@@ -62,18 +62,26 @@ def test_unpadded_step_equals_padded_step(hip):
     for batch in _batches(cfg, B):
         truth = orc.train_step({k: v.clone() for k, v in sd.items()}, cfg, table, batch, orc.AdamState(), max_grad_norm=0.0)["grads"]
         res = []
-        for unpad in (False, True):
+        for unpad, prune in ((False, False), (True, False), (True, True)):
             m = _model(cfg, sd, tsv_rows)
             m.train()
-            m.engine.unpad = unpad
+            m.engine.unpad, m.engine.prune_last_ffn = unpad, prune
             loss = float(m.forward_backward(batch))
             m.engine.join_wgrad()
             m.engine.check_errors()
             torch.cuda.synchronize()
             res.append((loss, [float(t) for t in m.last_loss_terms],
                         {k: v.detach().clone() for k, v in m.named_grad_views().items()}, list(m.engine.rows_executed)))
-        (l0, t0, g0, r0), (l1, t1, g1, r1) = res
+        (l0, t0, g0, r0), (l1, t1, g1, r1), (l2, t2, g2, r2) = res
         assert r0[0] == r0[1] == B * cfg.max_position_embeddings and r1[0] < r1[1]      # rows were dropped
+        # last-layer feed-forward block / pooler / head transform on the READ rows only (labelled + position 0): the same
+        # loss and gradients again, on a fraction of the rows (B * (1 + 2 * int(half * 0.15)) of them, rounded up to 64)
+        n_read = B + int((batch["masked_lm_labels"][:, 1:] != -100).sum()) + int((batch["ent_masked_lm_labels"] != -100).sum())
+        assert r1[5] == r1[0] and r2[0] == r1[0] and r2[5] == (n_read + 63) // 64 * 64 and r2[5] < r2[0] // 2
+        assert abs(l0 - l2) < 1e-4 * abs(l0) and np.allclose(t0, t2, rtol=2e-4, atol=1e-5)
+        errs2 = sorted(((_rel(g2[k], g0[k]), k) for k in g0), reverse=True)
+        print("pruned last layer vs padded, worst gradient tensors:", [(round(e, 5), k) for e, k in errs2[:3]])
+        assert errs2[0][0] < 1e-2 and errs2[len(errs2) // 2][0] < 2e-3, errs2[:3]
         kept = int(((batch["attention_mask"] != 0).any(1, keepdim=True) == 0).sum()) * cfg.max_position_embeddings
         assert r1[0] >= int((batch["attention_mask"] != 0).sum()) + kept - 64
         assert abs(l0 - l1) < 1e-4 * abs(l0), (l0, l1)
@@ -85,8 +93,9 @@ def test_unpadded_step_equals_padded_step(hip):
         for k, ref in truth.items():                       # against fp32 truth: packing loses nothing
             if k not in g0:
                 continue
-            e0, e1 = _rel(g0[k].cpu(), ref), _rel(g1[k].cpu(), ref)
-            assert e1 < max(1.3 * e0 + 2e-3, 8e-3) if float(ref.norm()) > 1e-6 else e1 < 1e-3, (k, e0, e1)
+            e0, e1, e2 = _rel(g0[k].cpu(), ref), _rel(g1[k].cpu(), ref), _rel(g2[k].cpu(), ref)
+            for e in (e1, e2):
+                assert e < max(1.3 * e0 + 2e-3, 8e-3) if float(ref.norm()) > 1e-6 else e < 1e-3, (k, e0, e1, e2)
         total0 = torch.sqrt(sum((g.double() ** 2).sum() for g in g0.values()))
         total1 = torch.sqrt(sum((g.double() ** 2).sum() for g in g1.values()))
         assert abs(float(total0) - float(total1)) < 1e-4 * float(total0)

@@ -243,16 +243,17 @@ def main():
 
     log("model + batches ready; warm-up")
     loss = None
-    for i in range(args.warmup):
-        loss = trainer.training_step(model, batches[i % len(batches)])
+    nb = len(batches)
+    for i in range(args.warmup):   # (every step is told the next batch, as Trainer.train does: its frozen-backbone forward
+        loss = trainer.training_step(model, batches[i % nb], next_inputs=batches[(i + 1) % nb])   # is queued a step ahead)
         if i == 0:
             torch.cuda.synchronize()
             log(f"first step done, loss {float(loss):.4f}")
     barrier()
     log("timed region")
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = trainer.training_step(model, batches[i % len(batches)])
+    for i in range(args.steps):   # (each timed step contains ONE backbone forward: the next batch's)
+        loss = trainer.training_step(model, batches[(args.warmup + i) % nb], next_inputs=batches[(args.warmup + i + 1) % nb])
     barrier()
     dt = time.perf_counter() - t0
     model.engine.check_errors()

@@ -106,6 +106,13 @@ class Engine:
         # READ rows only (labelled positions + position 0: ~77 of a sequence's ~410 rows) - they are row-wise, and nothing
         # reads the last layer's output at any other row. Attention and its projections still see every row (keys).
         self.prune_last_ffn = True
+        # The frozen backbone's forward depends on the batch's token ids and on frozen weights only: given a hint of the NEXT
+        # batch (`next_input_ids`, set by the trainer) it is queued on a stream of its own at the start of the current step and
+        # runs beside the current step's encoder forward, where no weight-gradient stream competes for the CUs.
+        self.next_input_ids: Optional[torch.Tensor] = None
+        self._prefetch: Optional[dict] = None
+        self._bb_stream: Optional[torch.cuda.Stream] = None
+        self._pref_par = 0
         # what ran: [rows, padded rows they stand for, encoder passes, sum over sequences of rows^2, of S^2] - bench.py prices
         # the step on the FLOPs actually executed (linear layers ~ rows, attention ~ rows^2 per sequence)
         self.rows_executed = [0, 0, 0, 0, 0, 0]   # (last: rows of the last layer's feed-forward block / pooler / head)
@@ -483,6 +490,39 @@ class Engine:
             x = self.layer_fwd(self.BB, f"lm_backbone.encoder.layer.{i}", x, B, seq, mask, p_hid, p_att, 101 + i, None)
         return x
 
+    def prefetch_backbone(self, input_ids, training: bool) -> None:
+        """Queue the frozen backbone's forward for a FUTURE batch on the backbone stream (ordered after everything queued so
+        far on the current stream: the ids are there, the previous prefetch's consumer has read its buffer). The result is
+        kept in one of two buffers until `encode` is called with the same ids."""
+        cfg = self.cfg
+        H, S, half = cfg.hidden_size, cfg.max_position_embeddings, cfg.half_length
+        B = input_ids.shape[0]
+        if self._bb_stream is None:
+            self._bb_stream = torch.cuda.Stream(device=self.device)
+        ready = torch.cuda.Event()
+        ready.record()
+        self._bb_stream.wait_event(ready)
+        self._pref_par ^= 1
+        out = self.buf(f"bb.pref{self._pref_par}", (B * half, H))
+        with torch.cuda.stream(self._bb_stream):
+            x = self.backbone_fwd(input_ids, S, B, half, training)
+            out.copy_(x)
+            done = torch.cuda.Event()
+            done.record()
+        self._prefetch = dict(ids=input_ids, ptr=input_ids.data_ptr(), ver=input_ids._version, shape=tuple(input_ids.shape),
+                              out=out, done=done, training=training)
+
+    def _take_prefetched(self, input_ids, training: bool):
+        """The prefetched backbone output for exactly these ids (same storage, same version, same mode), or None. Either
+        way the current stream is ordered after the prefetch: its scratch buffers are the inline forward's too."""
+        pf, self._prefetch = self._prefetch, None
+        if pf is None:
+            return None
+        torch.cuda.current_stream().wait_event(pf["done"])
+        hit = (pf["ptr"] == input_ids.data_ptr() and pf["ver"] == input_ids._version and
+               pf["shape"] == tuple(input_ids.shape) and pf["training"] == training)
+        return pf["out"] if hit else None
+
     def special_vectors(self) -> Dict[int, torch.Tensor]:
         """Quirk Q2: kg_backbone[sid] = lm_backbone([[sid]])[0][0][0], eval mode. A 1-token sequence is run as a
         128-token sequence whose only unmasked key is position 0 - identical arithmetic for that position."""
@@ -540,7 +580,12 @@ class Engine:
             plan, ev = self._plan_rows(attention_mask, unpad_labels[0], unpad_labels[1], B, S, half)
         # F1 frozen backbone (no attention mask: quirk Q5; always padded - its padding positions ARE attended)
         with self.block("K1 frozen backbone fwd"):
-            text_hidden = self.backbone_fwd(input_ids, S, B, half, training)
+            text_hidden = self._take_prefetched(input_ids, training)
+            if text_hidden is None:
+                text_hidden = self.backbone_fwd(input_ids, S, B, half, training)
+            hint, self.next_input_ids = self.next_input_ids, None
+            if hint is not None:
+                self.prefetch_backbone(hint, training)
         self.wait_params()   # everything above read frozen weights only; from here on the trainable ones
         T, rows, cu, mask, rd = cap, cap, None, attention_mask, None
         if plan is not None:

@@ -48,6 +48,9 @@ class TrainingArguments:
     # clip + AdamW + W^T refresh (and the tail of the gradient all-reduce) on their own stream, beside the next step's
     # frozen-backbone forward; parameters read through the model's accessors or after torch.cuda.synchronize() are final
     optimizer_overlap: bool = True
+    # queue the NEXT batch's frozen-backbone forward beside the current step's encoder forward (it depends on token ids and
+    # frozen weights only); needs the next batch: `Trainer.train` peeks it, `training_step(..., next_inputs=)` takes it
+    prefetch_backbone: bool = True
     # run the gradient collectives even when the process group has a single rank (hardware rehearsal of the N > 1 path)
     ddp_force_collectives: bool = False
     # ZeRO-2-style optimizer sharding (the reference can run DeepSpeed ZeRO-2: ref:stonkgs_pretraining.py:174-175): every
@@ -327,11 +330,32 @@ class Trainer:
         model.engine.comm_overlap = self.sync.active   # (see Engine.comm_overlap)
         self.global_step = 0
         self._micro = 0
+        self._next_cache = None
         self.log_history: List[dict] = []
 
     # hf:trainer.py:1892-1963 (+ the optimizer half of :1780-1796 when the accumulation window closes)
-    def training_step(self, model, inputs: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def _on_device(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """The batch as contiguous int64 device tensors; a batch handed over earlier as `next_inputs` is converted once."""
+        cached = self._next_cache
+        if cached is not None and cached[0] is batch:
+            return cached[1]
+        dev = self.model.device
+        ints = ("input_ids", "attention_mask", "token_type_ids", "masked_lm_labels", "ent_masked_lm_labels",
+                "next_sentence_labels")   # (anything else - a classification head's labels - is the model's to interpret)
+        return {k: (v if (k not in ints or (torch.is_tensor(v) and v.device == dev and v.dtype == torch.long and
+                                            v.is_contiguous()))
+                    else torch.as_tensor(v).to(device=dev, dtype=torch.long).contiguous()) for k, v in batch.items()}
+
+    def training_step(self, model, inputs: Dict[str, torch.Tensor], next_inputs: Optional[Dict] = None) -> torch.Tensor:
+        """`next_inputs` (optional): the batch of the NEXT call - its frozen-backbone forward is queued now, beside this
+        step's encoder forward (TrainingArguments.prefetch_backbone)."""
         model.train()
+        inputs = self._on_device(inputs)
+        self._next_cache = None
+        if next_inputs is not None and self.args.prefetch_backbone:
+            nxt = self._on_device(next_inputs)
+            self._next_cache = (next_inputs, nxt)
+            model.engine.next_input_ids = nxt["input_ids"]
         gas = self.args.gradient_accumulation_steps
         self._micro += 1
         last = self._micro % gas == 0
@@ -380,8 +404,11 @@ class Trainer:
         for _ in range(self.global_step * self.args.gradient_accumulation_steps):
             next(it)
         t0 = time.time()
+        batch = next(it)
         while self.global_step < self.args.max_steps:
-            loss = self.training_step(self.model, next(it))
+            upcoming = next(it)   # (known one step ahead: its frozen-backbone forward is queued beside this step)
+            loss = self.training_step(self.model, batch, next_inputs=upcoming)
+            batch = upcoming
             if self._micro % self.args.gradient_accumulation_steps == 0:
                 if self.global_step % self.args.logging_steps == 0 or self.global_step == self.args.max_steps:
                     self.model.engine.check_errors()

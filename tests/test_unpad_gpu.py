@@ -174,3 +174,31 @@ def test_unpadded_classification_step_equals_padded(hip):
     assert r1[0] < r0[0] and abs(l0 - l1) < 1e-4 * abs(l0)
     worst = max((_rel(g1[k], g0[k]), k) for k in g0)
     assert worst[0] < 1e-2, worst
+
+
+def test_backbone_prefetch_changes_nothing(hip):
+    """TrainingArguments.prefetch_backbone: the NEXT batch's frozen-backbone forward runs on its own stream beside the
+    current step (it depends on token ids and frozen weights only). Same losses with the hint, without it, and with a WRONG
+    hint (the prefetched result is dropped and the forward runs inline); host batches are converted once."""
+    from stonkgs_amd.stonkgs_pretraining import Trainer, TrainingArguments
+
+    cfg, sd, tsv_rows, _, _, _ = load_case("g2_hipsmall")
+    batches = _batches(cfg, 4) + _batches(cfg, 4)[::-1]
+    runs = {}
+    for mode in ("off", "hint", "wrong", "host"):
+        model = _model(cfg, sd, tsv_rows)
+        tr = Trainer(model, TrainingArguments(max_steps=10, learning_rate=1e-3, per_device_train_batch_size=4,
+                                              prefetch_backbone=mode != "off"))
+        bs = batches if mode == "host" else [{k: v.cuda() for k, v in b.items()} for b in batches]
+        losses = []
+        for i, b in enumerate(bs):
+            nxt = None if mode == "off" or i + 1 == len(bs) else (bs[i + 1] if mode != "wrong" else bs[0])
+            losses.append(float(tr.training_step(model, b, next_inputs=nxt)))
+            if mode in ("hint", "host") and nxt is not None:
+                assert model.engine._prefetch is not None and model.engine.next_input_ids is None
+        model.engine.check_errors()
+        torch.cuda.synchronize()
+        runs[mode] = losses
+    for mode in ("hint", "wrong", "host"):
+        assert runs[mode][0] == runs["off"][0], mode                       # the same kernels on the same data
+        assert np.allclose(runs[mode], runs["off"], rtol=0, atol=2e-3), (mode, runs[mode], runs["off"])

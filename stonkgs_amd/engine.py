@@ -583,9 +583,6 @@ class Engine:
             text_hidden = self._take_prefetched(input_ids, training)
             if text_hidden is None:
                 text_hidden = self.backbone_fwd(input_ids, S, B, half, training)
-            hint, self.next_input_ids = self.next_input_ids, None
-            if hint is not None:
-                self.prefetch_backbone(hint, training)
         self.wait_params()   # everything above read frozen weights only; from here on the trainable ones
         T, rows, cu, mask, rd = cap, cap, None, attention_mask, None
         if plan is not None:
@@ -616,6 +613,11 @@ class Engine:
                  self.kg_table.shape[0], cfg.type_vocab_size, cfg.layer_norm_eps, hip.LN_DROPOUT if p_hid > 0 else 0,
                  p_hid, self.seed(200, 0), self.err.data_ptr(), 0 if plan is None else plan["pos_of_row"].data_ptr(),
                  T if plan is not None else 0, st)
+        # the next batch's backbone forward, if the trainer named the batch: queued HERE - behind the kernel above, which
+        # was the last reader of an inline backbone forward's scratch buffers - to run beside the encoder forward below
+        hint, self.next_input_ids = self.next_input_ids, None
+        if hint is not None:
+            self.prefetch_backbone(hint, training)
         # F3 encoder
         span = self._span_begin()
         last = cfg.num_hidden_layers - 1

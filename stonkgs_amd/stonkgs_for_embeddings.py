@@ -63,27 +63,25 @@ def preprocess_df_for_embeddings_iter(rows: Iterable[Tuple[str, str, str]], *, e
         raise ValueError("embedding_name_to_vector_path and embedding_name_to_random_walk_path must be local TSV files")
     sep_id = 102 if sep_id is None else sep_id
     unk_id = 100 if unk_id is None else unk_id
-    kg_embed_dict = prepare_df(embedding_name_to_vector_path)
-    kg_name_to_idx = {key: i for i, key in enumerate(kg_embed_dict.keys())}       # TSV row order (quirk Q1's "preprocessing space")
-    random_walk_dict = prepare_df(embedding_name_to_random_walk_path)
-    random_walk_idx_dict = {k: [kg_name_to_idx[node] for node in v] for k, v in random_walk_dict.items()}
-    random_walk_length = len(next(iter(random_walk_idx_dict.values())))
-    half_length = random_walk_length * 2 + 2
-    if tokenizer is None:
-        tokenizer = _local_tokenizer(vocab_file_path, nlp_model_type)
-    vocab_len = len(tokenizer.vocab)
+    # node name -> its row in the embedding TSV (quirk Q1's "preprocessing space"), and every node's walk as such rows
+    row_of_node = {name: row for row, name in enumerate(prepare_df(embedding_name_to_vector_path))}
+    n_nodes = len(row_of_node)
+    walks = {node: [row_of_node[step] for step in walk]
+             for node, walk in prepare_df(embedding_name_to_random_walk_path).items()}
+    walk_len = len(next(iter(walks.values())))
+    half = 2 * walk_len + 2                      # walk [SEP] walk [SEP]
+    unknown = [unk_id] * walk_len                # a node without a walk: a walk of [UNK]s (ref :124-135)
+    tok = tokenizer if tokenizer is not None else _local_tokenizer(vocab_file_path, nlp_model_type)
+    n_tokens = len(tok.vocab)
+    segments = [0] * half + [1] * half
     for source, target, evidence in rows:
-        token_type_ids = [0] * half_length + [1] * half_length
-        encoded = tokenizer(evidence, padding="max_length", truncation=True, max_length=half_length)
-        text_token_ids, text_attention_mask = list(encoded["input_ids"]), list(encoded["attention_mask"])
-        walk_s = random_walk_idx_dict[source] if source in random_walk_idx_dict else [unk_id] * random_walk_length
-        walk_t = random_walk_idx_dict[target] if target in random_walk_idx_dict else [unk_id] * random_walk_length
-        random_walks = walk_s + [sep_id] + walk_t + [sep_id]
-        attention_mask = text_attention_mask + [1] * half_length
-        masked_ids, masked_lm_labels = replace_mlm_tokens(tokens=text_token_ids, vocab_len=vocab_len)
-        ent_ids, ent_masked_lm_labels = replace_mlm_tokens(tokens=random_walks, vocab_len=len(kg_embed_dict))
-        yield {"input_ids": masked_ids + ent_ids, "attention_mask": attention_mask, "token_type_ids": token_type_ids,
-               "masked_lm_labels": masked_lm_labels, "ent_masked_lm_labels": ent_masked_lm_labels,
+        enc = tok(evidence, padding="max_length", truncation=True, max_length=half)
+        entity_half = walks.get(source, unknown) + [sep_id] + walks.get(target, unknown) + [sep_id]
+        # (the two masking calls in the reference's order: text first - they share Python's random stream)
+        text_ids, text_labels = replace_mlm_tokens(tokens=list(enc["input_ids"]), vocab_len=n_tokens)
+        entity_ids, entity_labels = replace_mlm_tokens(tokens=entity_half, vocab_len=n_nodes)
+        yield {"input_ids": text_ids + entity_ids, "attention_mask": list(enc["attention_mask"]) + [1] * half,
+               "token_type_ids": list(segments), "masked_lm_labels": text_labels, "ent_masked_lm_labels": entity_labels,
                "next_sentence_labels": 0}
 
 

@@ -581,8 +581,16 @@ class Engine:
         # F1 frozen backbone (no attention mask: quirk Q5; always padded - its padding positions ARE attended)
         with self.block("K1 frozen backbone fwd"):
             text_hidden = self._take_prefetched(input_ids, training)
-            if text_hidden is None:
+            hit = text_hidden is not None
+            if not hit:
                 text_hidden = self.backbone_fwd(input_ids, S, B, half, training)
+            # The next batch's backbone forward, if the trainer named the batch. After a hit it is queued HERE, before the
+            # wait for the optimizer: it then runs beside AdamW (HBM-bound) and the encoder forward below. After a miss the
+            # inline forward's scratch buffers are still to be read by the embedding kernel: queued behind that kernel.
+            hint, self.next_input_ids = self.next_input_ids, None
+            if hint is not None and hit:
+                self.prefetch_backbone(hint, training)
+                hint = None
         self.wait_params()   # everything above read frozen weights only; from here on the trainable ones
         T, rows, cu, mask, rd = cap, cap, None, attention_mask, None
         if plan is not None:
@@ -613,10 +621,7 @@ class Engine:
                  self.kg_table.shape[0], cfg.type_vocab_size, cfg.layer_norm_eps, hip.LN_DROPOUT if p_hid > 0 else 0,
                  p_hid, self.seed(200, 0), self.err.data_ptr(), 0 if plan is None else plan["pos_of_row"].data_ptr(),
                  T if plan is not None else 0, st)
-        # the next batch's backbone forward, if the trainer named the batch: queued HERE - behind the kernel above, which
-        # was the last reader of an inline backbone forward's scratch buffers - to run beside the encoder forward below
-        hint, self.next_input_ids = self.next_input_ids, None
-        if hint is not None:
+        if hint is not None:   # (after an inline backbone forward: behind the kernel above, the last reader of its scratch)
             self.prefetch_backbone(hint, training)
         # F3 encoder
         span = self._span_begin()

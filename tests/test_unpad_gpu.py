@@ -200,5 +200,6 @@ def test_backbone_prefetch_changes_nothing(hip):
         torch.cuda.synchronize()
         runs[mode] = losses
     for mode in ("hint", "wrong", "host"):
-        assert runs[mode][0] == runs["off"][0], mode                       # the same kernels on the same data
+        # the same kernels on the same data (the loss sums are float atomics: equal up to their arrival order)
+        assert abs(runs[mode][0] - runs["off"][0]) < 1e-5 * abs(runs["off"][0]), mode
         assert np.allclose(runs[mode], runs["off"], rtol=0, atol=2e-3), (mode, runs[mode], runs["off"])

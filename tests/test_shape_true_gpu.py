@@ -212,3 +212,92 @@ def test_config4_24_layers_1024_wide(hip):
     worst = max(errs.items(), key=lambda t: t[1])
     print("config 4 worst gradient tensor:", worst)
     assert worst[1] < 8e-2, worst    # (the deepest layers' gradients pass through 24 layers of bf16 rounding)
+
+
+def test_config4_at_sequence_length_512(hip):
+    """BASELINE.json configs[3] names seq_len 512: the 24L / 1024h / 16 heads model at S = 512 (one sequence, small
+    vocabularies, so that the oracle's 24-layer fp32 step stays within a minute): loss terms, global gradient norm, every
+    gradient tensor - the training step's own path (packed rows, read-row pruning of the last layer)."""
+    from stonkgs_amd.data import synthetic_batch
+
+    cfg = orc.OracleConfig(vocab_size=2048, kg_vocab_size=640, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                           intermediate_size=4096, max_position_embeddings=512)
+    sd = orc.init_state_dict(cfg, seed=51)
+    g = torch.Generator().manual_seed(52)
+    tsv_rows = torch.randn(cfg.kg_vocab_size, cfg.hidden_size, generator=g, dtype=torch.float64) * 0.3
+    batch = synthetic_batch(1, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=53, min_text=40)
+    model = _build(cfg, sd, tsv_rows)
+    model.train()
+    model.zero_grad()
+    loss = model.forward_backward(batch)
+    model.engine.check_errors()
+    assert model.engine.rows_executed[0] < model.engine.rows_executed[1]          # the packed path ran
+    with torch.no_grad():
+        table = orc.build_kg_table(tsv_rows, orc.special_vectors(sd, cfg))
+    ref = orc.train_step(sd, cfg, table, batch, orc.AdamState(), max_grad_norm=0.0, base_lr=0.0)
+    terms = [float(t) for t in model.last_loss_terms]
+    d = [abs(float(loss) - float(ref["loss"]))] + [abs(t - float(ref[k])) for t, k in
+                                                   zip(terms, ("masked_lm_loss", "ent_masked_lm_loss", "next_sentence_loss"))]
+    print("config 4 at S = 512: |dloss|, |dterms| =", ["%.2e" % x for x in d])
+    assert max(d) < 1.5e-2
+    gv = model.named_grad_views()
+    tot = torch.sqrt(sum((v.double() ** 2).sum() for v in gv.values()))
+    assert abs(float(tot) - float(ref["grad_norm"])) < 3e-2 * float(ref["grad_norm"])
+    errs = {k: _rel(gv[k], ref["grads"][k]) for k in ref["grads"]}
+    worst = max(errs.items(), key=lambda t: t[1])
+    print("config 4 at S = 512, worst gradient tensor:", worst)
+    assert worst[1] < 8e-2, worst
+
+
+def test_config5_classification_head_on_the_12_layer_encoder(hip):
+    """BASELINE.json configs[4] on the encoder it names: STonKGsForSequenceClassification (ref:stonkgs_finetuning.py:237-346)
+    at 12L / 768h / 12 heads / S 512, two relation classes, a ragged batch of 3 - loss, logits and gradients against the
+    oracle's fp32 forward / autograd, through the training step (packed rows: the head reads position 0 only)."""
+    from stonkgs_amd.config import STonKGsConfig
+    from stonkgs_amd.data import synthetic_batch
+    from stonkgs_amd.stonkgs_model import STonKGsForSequenceClassification
+
+    cfg = orc.OracleConfig(kg_vocab_size=1000)
+    sd = orc.init_state_dict(cfg, seed=61)
+    gw = torch.Generator().manual_seed(62)
+    sd["classifier.weight"] = (torch.randn(2, cfg.hidden_size, generator=gw) * 0.02).to(torch.bfloat16).float()
+    sd["classifier.bias"] = (torch.randn(2, generator=gw) * 0.02).to(torch.bfloat16).float()
+    g = torch.Generator().manual_seed(63)
+    tsv_rows = torch.randn(cfg.kg_vocab_size, cfg.hidden_size, generator=g, dtype=torch.float64) * 0.3
+    b = synthetic_batch(3, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=64, min_text=16)
+    inputs = {k: b[k] for k in ("input_ids", "attention_mask", "token_type_ids")}
+    labels = torch.tensor([1, 0, 1])
+    c = STonKGsConfig(**{k: getattr(cfg, k) for k in ("vocab_size", "kg_vocab_size", "hidden_size", "num_hidden_layers",
+                                                      "num_attention_heads", "intermediate_size",
+                                                      "max_position_embeddings", "type_vocab_size", "layer_norm_eps")},
+                      hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, num_labels=2)
+    model = STonKGsForSequenceClassification(c, kg_embeddings=tsv_rows)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all("decoder" in k for k in missing)
+    model.train()
+    loss = float(model.forward_backward(dict(inputs, labels=labels)))
+    model.engine.join_wgrad()
+    model.engine.check_errors()
+    assert model.engine.rows_executed[5] == 64 and model.engine.rows_executed[0] < model.engine.rows_executed[1]
+    names = [k for k in sd if k.startswith("bert.") and "word_embeddings" not in k] + ["classifier.weight", "classifier.bias"]
+    params = {k: sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(sd)
+    work.update(params)
+    with torch.no_grad():
+        table = orc.build_kg_table(tsv_rows, orc.special_vectors(sd, cfg))
+    ref = orc.forward_classification(work, cfg, table, **inputs, labels=labels)
+    ref["loss"].backward()
+    print(f"config 5 on 12L/768: HIP loss {loss:.5f} oracle {float(ref['loss']):.5f}")
+    assert abs(loss - float(ref["loss"])) < 5e-3
+    model.eval()
+    with torch.no_grad():
+        out = model(**inputs, return_dict=True)
+    assert _rel(out.logits, ref["logits"].detach()) < 3e-2
+    gv = model.named_grad_views()
+    tot = torch.sqrt(sum((v.double() ** 2).sum() for v in gv.values()))
+    ref_tot = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values() if p.grad is not None))
+    assert abs(float(tot) - float(ref_tot)) < 4e-2 * float(ref_tot)
+    for k in ("classifier.weight", "bert.pooler.dense.weight", "bert.encoder.layer.11.output.dense.weight",
+              "bert.encoder.layer.11.attention.self.query.weight", "bert.encoder.layer.0.intermediate.dense.weight",
+              "bert.embeddings.position_embeddings.weight"):
+        assert _rel(gv[k], params[k].grad) < 8e-2, k

@@ -125,13 +125,17 @@ int stonk_unpad_plan(const int64_t* attention_mask, const int64_t* text_labels, 
  * q/k/v/out (any length <= S, no alignment), attention_mask is then REQUIRED and holds one word per packed ROW; lse (and
  * delta_ws) keep the [B,NH,S] layout. What the trainable encoder runs on once the rows that nothing reads - padding that
  * is neither a live key nor a labelled position - are dropped (stonk_unpad_plan); rows outside every sequence are never
- * read or written. */
+ * read or written. q_offsets (nullable, int32 [B+1], packed layout only): sequence b's QUERIES are its first
+ * q_offsets[b+1] - q_offsets[b] rows (its keys: all of them) - out / lse / dq are written for those rows only, dk / dv
+ * receive their contributions only. The last encoder layer's form: stonk_unpad_plan puts a sequence's read rows first. */
 int stonk_attention_fwd(const void* q, const void* k, const void* v, int64_t ld, const int64_t* attention_mask,
-                        const int* seq_offsets, void* out, int64_t ldo, float* lse, int B, int NH, int S, int D,
-                        float scale, float drop_p, uint32_t seed, void* stream);
-/* Backward of the above (recomputes P from lse; no atomics). delta_ws: fp32 [B,NH,S] scratch. */
+                        const int* seq_offsets, const int* q_offsets, void* out, int64_t ldo, float* lse, int B, int NH,
+                        int S, int D, float scale, float drop_p, uint32_t seed, void* stream);
+/* Backward of the above (recomputes P from lse; no atomics). delta_ws: fp32 [B,NH,S] scratch. With q_offsets, dq rows
+ * past a sequence's queries are NOT written (zero them if something reads them) and dout rows past them must be finite. */
 int stonk_attention_bwd(const void* q, const void* k, const void* v, int64_t ld, const int64_t* attention_mask,
-                        const int* seq_offsets, const void* out, int64_t ldo, const void* dout, int64_t lddo,
+                        const int* seq_offsets, const int* q_offsets, const void* out, int64_t ldo, const void* dout,
+                        int64_t lddo,
                         const float* lse, float* delta_ws, void* dq, void* dk, int64_t ldd, void* dv, int B, int NH,
                         int S, int D, float scale, float drop_p, uint32_t seed, void* stream);
 

@@ -93,7 +93,7 @@ def assemble_rows(text_ids, text_attention, source, target, walks, sep_id=102, n
 
 def unpad_plan(attention_mask, text_labels=None, ent_labels=None, read=False):
     """numpy restatement of stonkgs_amd/csrc/unpad.hip (stonk_unpad_plan): which padded positions the trainable encoder
-    keeps, in position order. Kept: attention_mask != 0, position 0 (the pooler's input, hf:modeling_bert.py:457-463),
+    keeps. Kept: attention_mask != 0, position 0 (the pooler's input, hf:modeling_bert.py:457-463),
     a labelled position of either half (the reference labels 15 % of the PADDED half,
     ref:src/stonkgs/data/indra_for_pretraining.py:33-77, and nn.CrossEntropyLoss reads those rows,
     ref:src/stonkgs/models/stonkgs_model.py:229-240); a sequence without any unmasked key keeps everything (the reference
@@ -106,33 +106,37 @@ def unpad_plan(attention_mask, text_labels=None, ent_labels=None, read=False):
     half = S // 2
     keep = am != 0
     keep[:, 0] = True
-    if text_labels is not None:
-        keep[:, :half] |= np.asarray(text_labels) != -100
-    if ent_labels is not None:
-        keep[:, half:] |= np.asarray(ent_labels) != -100
-    keep[~(am != 0).any(axis=1)] = True
-    flat = keep.reshape(-1)
-    total = int(flat.sum())
-    row_of_pos = np.full(B * S, -1, dtype=np.int32)
-    row_of_pos[flat] = np.arange(total, dtype=np.int32)
-    pos_of_row = np.full(B * S, -1, dtype=np.int32)
-    pos_of_row[:total] = np.nonzero(flat)[0].astype(np.int32)
-    seq_offsets = np.concatenate([[0], np.cumsum(keep.sum(axis=1))]).astype(np.int32)
-    row_mask = np.zeros(B * S, dtype=np.int64)
-    row_mask[:total] = am.reshape(-1)[flat]
-    if not read:
-        return row_of_pos, pos_of_row, seq_offsets, row_mask
-    rd = np.zeros((B, S), dtype=bool)
+    rd = np.zeros((B, S), dtype=bool)          # READ rows: labelled positions and position 0
     rd[:, 0] = True
     if text_labels is not None:
         rd[:, :half] |= np.asarray(text_labels) != -100
     if ent_labels is not None:
         rd[:, half:] |= np.asarray(ent_labels) != -100
-    rflat = rd.reshape(-1)
-    n_rd = int(rflat.sum())
+    keep |= rd
+    keep[~(am != 0).any(axis=1)] = True
+    # a sequence's packed rows: its read rows first (position order), then its other kept rows (position order)
+    row_of_pos = np.full(B * S, -1, dtype=np.int32)
+    pos_of_row = np.full(B * S, -1, dtype=np.int32)
+    seq_offsets = np.zeros(B + 1, dtype=np.int32)
+    read_offsets = np.zeros(B + 1, dtype=np.int32)
     read_rows = np.full(B * S, -1, dtype=np.int32)
-    read_rows[:n_rd] = row_of_pos[rflat]
     read_of_pos = np.full(B * S, -1, dtype=np.int32)
-    read_of_pos[rflat] = np.arange(n_rd, dtype=np.int32)
-    read_offsets = np.concatenate([[0], np.cumsum(rd.sum(axis=1))]).astype(np.int32)
+    row = nr = 0
+    for b in range(B):
+        first = np.nonzero(rd[b])[0]
+        rest = np.nonzero(keep[b] & ~rd[b])[0]
+        for j, s in enumerate(first):
+            read_rows[nr + j] = row + j
+            read_of_pos[b * S + s] = nr + j
+        for s in np.concatenate([first, rest]):
+            row_of_pos[b * S + s] = row
+            pos_of_row[row] = b * S + s
+            row += 1
+        nr += len(first)
+        seq_offsets[b + 1], read_offsets[b + 1] = row, nr
+    total = row
+    row_mask = np.zeros(B * S, dtype=np.int64)
+    row_mask[:total] = am.reshape(-1)[pos_of_row[:total]]
+    if not read:
+        return row_of_pos, pos_of_row, seq_offsets, row_mask
     return row_of_pos, pos_of_row, seq_offsets, row_mask, read_rows, read_of_pos, read_offsets

@@ -38,6 +38,7 @@ struct AttnArgs {
   long ld;            // row stride (elements) of q/k/v
   const long* mask;   // [B,S] or null; with `cu`: one word per ROW of the packed layout (required)
   const int* cu;      // null, or [B+1] row offsets: sequence b = rows cu[b] .. cu[b+1]-1 of q/k/v/out/dout/dq/dk/dv (<= S rows)
+  const int* qoff;    // null, or [B+1]: only the first qoff[b+1] - qoff[b] rows of sequence b are QUERIES (keys: all of them)
   bf16* out;          // fwd: context [T, ldo]; bwd: the forward's context (read)
   long ldo;
   float* lse;         // [B, NH, S] natural-log LSE of the scaled+masked scores
@@ -227,6 +228,15 @@ __device__ __forceinline__ AttnBlock attn_block() {
   }                                                                      \
   if (blk.xb * 128 >= n) return
 
+// Query rows of the block's sequence: all n, or - the last encoder layer, whose output is read at a sequence's first rows
+// only (stonk_unpad_plan puts the read rows there) - its first p.qoff[b+1] - p.qoff[b].
+#define QUERY_EXTENT()                          \
+  int nq = n;                                   \
+  if (p.qoff) {                                 \
+    const int lim = p.qoff[b + 1] - p.qoff[b];  \
+    nq = lim < n ? lim : n;                     \
+  }
+
 // Key tiles (64 keys) of a sequence that hold at least one unmasked key, one bit per tile: a fully masked tile adds
 // exactly nothing to any query (its scores are -2^100 in raw units, their exp2 is 0), so the kernels with the keys in the
 // tile loop walk the set bits only - in the STonKGs layout the padding of the text half, 112 of 512 positions on average
@@ -275,6 +285,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
   const int S = p.S;
   const int q0 = blk.xb * 128 + wave * 32;
   SEQ_EXTENT();
+  QUERY_EXTENT();
+  if (blk.xb * 128 >= nq) return;
   const float sc2 = p.scale * LOG2E;
   LiveTiles lt;
   live_issue<HAS_MASK>(lt, p.mask, tok0, n, tid);
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
     kt = nx;
   }
   const float inv = (DROPOUT ? p.drop_scale : 1.f) / l;
-  if (q0 + r >= n) return;
+  if (q0 + r >= nq) return;
   bf16* orow = p.out + (tok0 + q0 + r) * p.ldo + h * HD;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -422,10 +434,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const int S = p.S;
   const int q0 = blk.xb * 128 + wave * 32;
   SEQ_EXTENT();
+  QUERY_EXTENT();
+  if (blk.xb * 128 >= nq) return;
   LiveTiles lt;
   live_issue<HAS_MASK>(lt, p.mask, tok0, n, tid);
 
-  const bool qlive = q0 + r < n;
+  const bool qlive = q0 + r < nq;
   const int qr = qlive ? q0 + r : n - 1;   // rows past the sequence re-read its last row; nothing is stored for them
   bf16x8 qf[4], dof[4];
   float dlt = 0.f;
@@ -566,6 +580,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   const int S = p.S;
   const int k0 = blk.xb * 128 + wave * 32;
   SEQ_EXTENT();
+  QUERY_EXTENT();
   LiveTiles lt;
   live_issue<HAS_MASK>(lt, p.mask, tok0, n, tid);
 
@@ -594,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   const bf16* qbase = p.q + tok0 * p.ld + h * HD;
   const bf16* dbase = p.dout + tok0 * p.lddo + h * HD;
   const long statbase = (long)(b * p.NH + h) * S;
-  const int ntiles = (n + TK - 1) / TK;
+  const int ntiles = (nq + TK - 1) / TK;   // QUERY tiles
   const uint32_t rk_lane = stonk_rowkey((uint32_t)(statbase + 4 * hh), p.seed);
   const uint32_t ck = stonk_colkey((uint32_t)((k0 + r) >> 2));   // this lane's key: its quad ...
   const uint32_t c2 = stonk_quad_c2((uint32_t)(k0 + r));         // ... and its place in it
@@ -613,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
     stage_load(sq, qbase, p.ld, qt * TK, n, tid);
     stage_load(sd, dbase, p.lddo, qt * TK, n, tid);
     if (tid < 2 * TK) {
-      slive = qt * TK + (tid & (TK - 1)) < n;
+      slive = qt * TK + (tid & (TK - 1)) < nq;
       sreg = sptr[qt * TK];      // (inside the [B,NH,S] statistics arrays also past the sequence: S % 128 == 0)
     }
   };
@@ -735,18 +750,19 @@ int check_common(const void* q, const void* k, const void* v, int64_t ld, int B,
 }  // namespace
 
 extern "C" int stonk_attention_fwd(const void* q, const void* k, const void* v, int64_t ld,
-                                   const int64_t* attention_mask, const int* seq_offsets, void* out, int64_t ldo,
-                                   float* lse, int B, int NH, int S, int D, float scale, float drop_p, uint32_t seed,
-                                   void* stream) {
+                                   const int64_t* attention_mask, const int* seq_offsets, const int* q_offsets, void* out,
+                                   int64_t ldo, float* lse, int B, int NH, int S, int D, float scale, float drop_p,
+                                   uint32_t seed, void* stream) {
   int rc = check_common(q, k, v, ld, B, NH, S, D);
   if (rc) return rc;
   STONK_CHECK_ARG(out && ldo % 4 == 0, STONK_EINVAL);
   STONK_CHECK_ARG(!seq_offsets || attention_mask, STONK_EINVAL);   // packed rows carry their key mask
+  STONK_CHECK_ARG(!q_offsets || seq_offsets, STONK_EINVAL);
   STONK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, STONK_EINVAL);
   if (B == 0) return STONK_OK;
   AttnArgs a = {};
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
-  a.mask = (const long*)attention_mask; a.cu = seq_offsets; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse;
+  a.mask = (const long*)attention_mask; a.cu = seq_offsets; a.qoff = q_offsets; a.out = (bf16*)out; a.ldo = ldo; a.lse = lse;
   a.B = B; a.NH = NH; a.S = S; a.scale = scale;
   a.drop_thr32 = stonk_drop_thr32(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = stonk_seed_mix(seed);
   const dim3 grid(S / 128, NH, B), block(256);
@@ -760,7 +776,8 @@ extern "C" int stonk_attention_fwd(const void* q, const void* k, const void* v, 
 }
 
 extern "C" int stonk_attention_bwd(const void* q, const void* k, const void* v, int64_t ld,
-                                   const int64_t* attention_mask, const int* seq_offsets, const void* out, int64_t ldo, const void* dout,
+                                   const int64_t* attention_mask, const int* seq_offsets, const int* q_offsets,
+                                   const void* out, int64_t ldo, const void* dout,
                                    int64_t lddo, const float* lse, float* delta_ws, void* dq, void* dk, int64_t ldd,
                                    void* dv, int B, int NH, int S, int D, float scale, float drop_p, uint32_t seed,
                                    void* stream) {
@@ -768,12 +785,13 @@ extern "C" int stonk_attention_bwd(const void* q, const void* k, const void* v, 
   if (rc) return rc;
   STONK_CHECK_ARG(out && dout && lse && delta_ws && dq && dk && dv, STONK_EINVAL);
   STONK_CHECK_ARG(!seq_offsets || attention_mask, STONK_EINVAL);
+  STONK_CHECK_ARG(!q_offsets || seq_offsets, STONK_EINVAL);
   STONK_CHECK_ARG(ldo % 8 == 0 && lddo % 8 == 0 && ldd % 4 == 0, STONK_EALIGN);
   STONK_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, STONK_EINVAL);
   if (B == 0) return STONK_OK;
   AttnArgs a = {};
   a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
-  a.mask = (const long*)attention_mask; a.cu = seq_offsets; a.lse = (float*)lse; a.out = (bf16*)out; a.ldo = ldo;
+  a.mask = (const long*)attention_mask; a.cu = seq_offsets; a.qoff = q_offsets; a.lse = (float*)lse; a.out = (bf16*)out; a.ldo = ldo;
   a.dout = (const bf16*)dout; a.lddo = lddo; a.delta = delta_ws;
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ldd = ldd;
   a.B = B; a.NH = NH; a.S = S; a.scale = scale;

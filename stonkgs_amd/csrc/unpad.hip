@@ -9,6 +9,10 @@
 // In the benchmark's batches (text length uniform in [32, 256]) that is 95 of 512 positions.
 //
 // This kernel pair turns (attention_mask, labels) into the packed layout the engine then runs on:
+// Order of a sequence's packed rows: its READ rows first (labelled positions and position 0, in position order), then its
+// other kept rows (position order). Attention does not care about the order of a sequence's rows (positions live in the
+// embeddings), every other operation is row-wise - and the rows whose last-layer output is read sit at the head of each
+// sequence, where the last layer's attention can stop (stonk_attention_* `q_limit`).
 //   row_of_pos [B*S]  packed row of padded position b*S+s, or -1 for a dropped position
 //   pos_of_row [B*S]  padded position of packed row i (i < total), -1 beyond
 //   seq_offsets[B+1]  first packed row of every sequence; [B] = total (what stonk_attention_* take as `seq_offsets`)
@@ -144,30 +148,31 @@ __global__ __launch_bounds__(TPB) void unpad_fill_kernel(const long* __restrict_
   const bool any_live = live_flags[b] != 0;
   const int per = (S + TPB - 1) / TPB;
   const int s0 = threadIdx.x * per, s1 = s0 + per < S ? s0 + per : S;
-  int cnt = 0, rd = 0;
+  int cnt_r = 0, cnt_o = 0;   // read rows / other kept rows of this thread's chunk
   for (int s = s0; s < s1; ++s) {
-    cnt += keep_position(mask, text_labels, ent_labels, b, s, S, half, any_live);
-    rd += read_position(text_labels, ent_labels, b, s, half);
+    const bool rdp = read_position(text_labels, ent_labels, b, s, half);
+    cnt_r += rdp;
+    cnt_o += !rdp && keep_position(mask, text_labels, ent_labels, b, s, S, half, any_live);
   }
   int total;
-  int row = before + block_excl_scan(cnt, &total);
-  int rrow = rbefore + block_excl_scan(rd, &total);
+  int row_r = before + block_excl_scan(cnt_r, &total);
+  const int n_read_b = total;                         // (= counts[2B + b])
+  int row_o = before + n_read_b + block_excl_scan(cnt_o, &total);
   for (int s = s0; s < s1; ++s) {
     const long p = (long)b * S + s;
-    const bool kept = keep_position(mask, text_labels, ent_labels, b, s, S, half, any_live);
+    const bool rdp = read_position(text_labels, ent_labels, b, s, half);
+    const bool kept = rdp || keep_position(mask, text_labels, ent_labels, b, s, S, half, any_live);
+    const int row = rdp ? row_r++ : (kept ? row_o++ : -1);
+    row_of_pos[p] = row;
     if (kept) {
-      row_of_pos[p] = row;
       pos_of_row[row] = (int)p;
       row_mask[row] = mask[p];
-    } else {
-      row_of_pos[p] = -1;
     }
-    if (read_rows) {   // (a read position is always a kept one)
-      const bool rdp = read_position(text_labels, ent_labels, b, s, half);
-      read_of_pos[p] = rdp ? rrow : -1;
-      if (rdp) read_rows[rrow++] = row;
+    if (read_rows) {
+      const int ri = rdp ? rbefore + (row - before) : -1;   // read rows are the first n_read_b rows of the sequence
+      read_of_pos[p] = ri;
+      if (rdp) read_rows[ri] = row;
     }
-    row += kept;
   }
   if (threadIdx.x == 0) {
     seq_offsets[b] = before;

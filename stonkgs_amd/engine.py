@@ -106,6 +106,10 @@ class Engine:
         # READ rows only (labelled positions + position 0: ~77 of a sequence's ~410 rows) - they are row-wise, and nothing
         # reads the last layer's output at any other row. Attention and its projections still see every row (keys).
         self.prune_last_ffn = True
+        # ... and so does the last layer's attention block behind the QKV projection: the row plan puts a sequence's read
+        # rows first, the attention kernels compute the first rows of every sequence as queries only (`q_offsets`; keys and
+        # values: every row), and the output projection + LayerNorm run on the gathered read rows.
+        self.prune_last_attn = True
         # The frozen backbone's forward depends on the batch's token ids and on frozen weights only: given a hint of the NEXT
         # batch (`next_input_ids`, set by the trainer) it is queued on a stream of its own at the start of the current step and
         # runs beside the current step's encoder forward, where no weight-gradient stream competes for the CUs.
@@ -345,21 +349,30 @@ class Engine:
         # attention kernel and must stay finite for the projections that run over them)
         ctx = self.buf(f"{tag}.ctx", (cap, H), zero=True)
         lse = self.buf(f"{tag}.lse", (B, NH, seq), F32)
+        qattn = rd is not None and rd.get("attn", False)   # queries = the read rows only (a sequence's first rows)
+        qoff = rd["offsets"] if qattn else None
         hip.call("stonk_attention_fwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H,
-                 hip.ptr(mask), hip.ptr(cu), ctx.data_ptr(), H, lse.data_ptr(), B, NH, seq, 64, 1.0 / math.sqrt(64.0),
-                 p_att, self.seed(lidx, 1), st)
+                 hip.ptr(mask), hip.ptr(cu), hip.ptr(qoff), ctx.data_ptr(), H, lse.data_ptr(), B, NH, seq, 64,
+                 1.0 / math.sqrt(64.0), p_att, self.seed(lidx, 1), st)
+        Ta, a_in, res = T, ctx, x                  # rows / input / residual of the output projection
+        if qattn:
+            Ta = rd["T"]
+            a_in, res = self.buf(f"{tag}.ctxrd", (cap, H)), self.buf(f"{tag}.xrd", (cap, H))
+            for src, dst in ((ctx, a_in), (x, res)):   # (rows from the count up to the next multiple of 128 are zero-filled)
+                hip.call("stonk_gather_rows_bf16", src.data_ptr(), H, rd["rows"].data_ptr(), rd["cnt"].data_ptr(),
+                         dst.data_ptr(), H, H, cap, st)
         s1 = self.buf(f"{tag}.s1", (cap, H))
         fl = hip.EPI_BIAS | hip.EPI_RESID | (hip.EPI_DROPOUT if p_hid > 0 else 0)
-        self.gemm(ctx, w(prefix + ".attention.output.dense.weight"), s1, T, H, H, flags=fl,
-                  bias=f(prefix + ".attention.output.dense.bias"), resid=x, drop_p=p_hid, seed=self.seed(lidx, 2),
+        self.gemm(a_in, w(prefix + ".attention.output.dense.weight"), s1, Ta, H, H, flags=fl,
+                  bias=f(prefix + ".attention.output.dense.bias"), resid=res, drop_p=p_hid, seed=self.seed(lidx, 2),
                   kernel=self._kernel("attn_out"))
         h1 = self.buf(f"{tag}.h1", (cap, H))
         st1 = self.buf(f"{tag}.st1", (2, cap), F32)
         hip.call("stonk_layernorm_fwd", s1.data_ptr(), f(prefix + ".attention.output.LayerNorm.weight").data_ptr(),
                  f(prefix + ".attention.output.LayerNorm.bias").data_ptr(), h1.data_ptr(), st1[0].data_ptr(),
-                 st1[1].data_ptr(), T, H, cfg.layer_norm_eps, 0, 0.0, 0, st)
-        hf, Tf = h1, T                             # input rows of the feed-forward block
-        if rd is not None:
+                 st1[1].data_ptr(), Ta, H, cfg.layer_norm_eps, 0, 0.0, 0, st)
+        hf, Tf = h1, Ta                            # input rows of the feed-forward block
+        if rd is not None and not qattn:
             hf, Tf = self.buf(f"{tag}.h1rd", (cap, H)), rd["T"]
             hip.call("stonk_gather_rows_bf16", h1.data_ptr(), H, rd["rows"].data_ptr(), rd["cnt"].data_ptr(), hf.data_ptr(),
                      H, H, cap, st)            # (rows from the count up to the next multiple of 128 are zero-filled)
@@ -378,7 +391,7 @@ class Engine:
                  f(prefix + ".output.LayerNorm.bias").data_ptr(), y.data_ptr(), st2[0].data_ptr(), st2[1].data_ptr(), Tf,
                  H, cfg.layer_norm_eps, 0, 0.0, 0, st)
         if save is not None:
-            save[prefix] = dict(x=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, h1=hf, st1=st1, g=g, u=u, s2=s2, st2=st2)
+            save[prefix] = dict(x=x, qkv=qkv, ctx=ctx, ctx_in=a_in, lse=lse, s1=s1, h1=hf, st1=st1, g=g, u=u, s2=s2, st2=st2)
         return y
 
     def layer_bwd(self, prefix: str, dy, B, seq, mask, p_hid, p_att, lidx, sv, T: Optional[int] = None, cu=None,
@@ -419,9 +432,11 @@ class Engine:
         # ---- FFN up
         self.wgrad(du, sv["h1"], g_(prefix + ".intermediate.dense.weight"), g_(prefix + ".intermediate.dense.bias"), I, H,
                    Tf)
+        qattn = rd is not None and rd.get("attn", False)
+        Ta = Tf if qattn else T                    # rows the attention block's projection / LayerNorm ran on
         dh1 = self.buf("b.dh1", (cap, H))
-        if rd is None:
-            self.gemm(du, wt[prefix + ".intermediate.dense.weight"], dh1, T, H, I, flags=hip.EPI_RESID, resid=ds2,
+        if rd is None or qattn:
+            self.gemm(du, wt[prefix + ".intermediate.dense.weight"], dh1, Tf, H, I, flags=hip.EPI_RESID, resid=ds2,
                       kernel=self._kernel("dgrad_resid", True))
         else:   # gradient of the gathered rows, scattered into an otherwise zero gradient of the attention block's output
             dh1rd = self.buf("b.dh1rd", (cap, H))
@@ -436,26 +451,40 @@ class Engine:
         hip.call("stonk_layernorm_bwd", dh1.data_ptr(), sv["s1"].data_ptr(), sv["st1"][0].data_ptr(),
                  sv["st1"][1].data_ptr(), f(prefix + ".attention.output.LayerNorm.weight").data_ptr(), ds1.data_ptr(),
                  hip.ptr(da), g_(prefix + ".attention.output.LayerNorm.weight").data_ptr(),
-                 g_(prefix + ".attention.output.LayerNorm.bias").data_ptr(), T, H, 0, 0.0, 0, p_hid, self.seed(lidx, 2),
+                 g_(prefix + ".attention.output.LayerNorm.bias").data_ptr(), Ta, H, 0, 0.0, 0, p_hid, self.seed(lidx, 2),
                  self.ln_ws().data_ptr(), self.ln_ws().numel(), st)
         if da is None:
             da = ds1
         # ---- attention output projection
-        self.wgrad(da, sv["ctx"], g_(prefix + ".attention.output.dense.weight"),
-                   g_(prefix + ".attention.output.dense.bias"), H, H, T)
+        self.wgrad(da, sv["ctx_in"], g_(prefix + ".attention.output.dense.weight"),
+                   g_(prefix + ".attention.output.dense.bias"), H, H, Ta)
         dctx = self.buf("b.dctx", (cap, H))
-        self.gemm(da, wt[prefix + ".attention.output.dense.weight"], dctx, T, H, H,
-                  kernel=self._kernel("dgrad_attn_out", True))
+        if not qattn:
+            self.gemm(da, wt[prefix + ".attention.output.dense.weight"], dctx, T, H, H,
+                      kernel=self._kernel("dgrad_attn_out", True))
+        else:   # the read rows' gradients go back to their packed rows: into zeros (the kernels read whole query tiles)
+            dctxrd, ds1rd = self.buf("b.dctxrd", (cap, H)), ds1
+            self.gemm(da, wt[prefix + ".attention.output.dense.weight"], dctxrd, Ta, H, H,
+                      kernel=self._kernel("dgrad_attn_out", True))
+            ds1 = self.buf("b.ds1full", (cap, H))
+            for src, dst in ((dctxrd, dctx), (ds1rd, ds1)):
+                dst[:T].zero_()
+                hip.call("stonk_scatter_rows_bf16", src.data_ptr(), H, rd["rows"].data_ptr(), rd["cnt"].data_ptr(),
+                         dst.data_ptr(), H, H, st)
         # ---- attention core
         qkv = sv["qkv"]
         dqkv = self.buf(f"b.dqkv.{par}", (cap, 3 * H))
         delta = self.buf("b.delta", (B, NH, seq), F32)
-        if cu is not None and rows is not None and rows < T:
+        qoff = rd["offsets"] if qattn else None
+        if qattn:
+            dqkv[:T].zero_()   # dQ of the rows that were not queries (the kernel does not write them) feeds the projection's gradients
+        elif cu is not None and rows is not None and rows < T:
             # the rows between the last sequence and T are not the attention kernel's to write, and the weight gradient
             # below contracts over all T rows: what an earlier step left there must not reach dW
             dqkv[rows:T].zero_()
         hip.call("stonk_attention_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H,
-                 hip.ptr(mask), hip.ptr(cu), sv["ctx"].data_ptr(), H, dctx.data_ptr(), H, sv["lse"].data_ptr(), delta.data_ptr(),
+                 hip.ptr(mask), hip.ptr(cu), hip.ptr(qoff), sv["ctx"].data_ptr(), H, dctx.data_ptr(), H, sv["lse"].data_ptr(),
+                 delta.data_ptr(),
                  dqkv.data_ptr(), dqkv.data_ptr() + 2 * H, 3 * H, dqkv.data_ptr() + 4 * H, B, NH, seq, 64,
                  1.0 / math.sqrt(64.0), p_att, self.seed(lidx, 1), st)
         # ---- QKV projection
@@ -602,8 +631,8 @@ class Engine:
             cu, mask = plan["cu"], plan["row_mask"]
             sq = sum((offs[i + 1] - offs[i]) ** 2 for i in range(B))
             if self.prune_last_ffn:
-                rd = dict(rows=plan["read_rows"], cnt=plan["cu_rd"][B:B + 1], n=n_read,
-                          T=min(cap, (n_read + 63) // 64 * 64))
+                rd = dict(rows=plan["read_rows"], cnt=plan["cu_rd"][B:B + 1], n=n_read, offsets=plan["cu_rd"],
+                          T=min(cap, (n_read + 63) // 64 * 64), attn=self.prune_last_attn)
         else:
             sq = B * S * S
         Th = T if rd is None else rd["T"]          # rows of the sequence output (and of everything the heads run on)

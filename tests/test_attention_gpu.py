@@ -25,21 +25,21 @@ def _ref(qkv, mask, B, S, NH, dout=None):
     return o.detach(), lse.detach(), grads
 
 
-def _run_fwd(hip, qkv, mask, B, S, NH, drop_p=0.0, seed=0, cu=None):
+def _run_fwd(hip, qkv, mask, B, S, NH, drop_p=0.0, seed=0, cu=None, qoff=None):
     H = NH * 64
     out = torch.full((qkv.shape[0], H), 7.0, device="cuda", dtype=torch.bfloat16)
     lse = torch.full((B, NH, S), float("nan"), device="cuda")
     hip.call("stonk_attention_fwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask),
-             hip.ptr(cu), hip.ptr(out), H, hip.ptr(lse), B, NH, S, 64, 0.125, drop_p, seed, hip.stream_ptr())
+             hip.ptr(cu), hip.ptr(qoff), hip.ptr(out), H, hip.ptr(lse), B, NH, S, 64, 0.125, drop_p, seed, hip.stream_ptr())
     return out, lse
 
 
-def _run_bwd(hip, qkv, mask, out, dout, lse, B, S, NH, drop_p=0.0, seed=0, cu=None):
+def _run_bwd(hip, qkv, mask, out, dout, lse, B, S, NH, drop_p=0.0, seed=0, cu=None, qoff=None):
     H = NH * 64
     dqkv = torch.zeros_like(qkv)
     delta = torch.full((B, NH, S), float("nan"), device="cuda")
     hip.call("stonk_attention_bwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask),
-             hip.ptr(cu), hip.ptr(out), H, hip.ptr(dout), H, hip.ptr(lse), hip.ptr(delta), hip.ptr(dqkv),
+             hip.ptr(cu), hip.ptr(qoff), hip.ptr(out), H, hip.ptr(dout), H, hip.ptr(lse), hip.ptr(delta), hip.ptr(dqkv),
              hip.ptr(dqkv) + 2 * H, 3 * H, hip.ptr(dqkv) + 4 * H, B, NH, S, 64, 0.125, drop_p, seed, hip.stream_ptr())
     return dqkv
 
@@ -299,6 +299,57 @@ def test_attention_packed_sequences_of_any_length(hip, drop_p):
         g1 = _run_bwd(hip, qkv, mask, o1, dout, l1, B, S, NH, drop_p, 9, cu=cu_d)
         g2 = _run_bwd(hip, qkv, mask, o1, dout, l1, B, S, NH, drop_p, 9, cu=cu_d)
         assert torch.equal(g1, g2) and bool(torch.isfinite(g1).all())
+
+
+def test_attention_query_limits(hip):
+    """`q_offsets`: only the first rows of every packed sequence are queries (the last encoder layer: the row plan puts the
+    rows whose output is read there); keys and values are all of a sequence's rows. out / lse / dQ for those rows equal
+    torch's on the full sequence, rows past them are not written; dK / dV are the contributions of THOSE queries only (a
+    torch backward with zero output gradient elsewhere). Limits of 0, 1, 64, 77, a whole sequence; dropout replay."""
+    S, NH = 512, 2
+    H = NH * 64
+    lens = [417, 130, 512, 64, 300]
+    nq = [77, 1, 512, 64, 0]
+    B = len(lens)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    qo = torch.tensor([0] + list(torch.tensor(nq).cumsum(0)), dtype=torch.int32)
+    T = int(cu[-1])
+    g = torch.Generator(device="cuda").manual_seed(15)
+    qkv = (torch.randn(T, 3 * H, device="cuda", generator=g) * 1.5).to(torch.bfloat16)
+    dout = torch.randn(T, H, device="cuda", generator=g).to(torch.bfloat16)
+    mask = torch.ones(T, dtype=torch.long)
+    mask[20:37] = 0                                        # masked rows among sequence 0's queries (labelled padding)
+    mask, cu_d, qo_d = mask.cuda(), cu.cuda(), qo.cuda()
+    out, lse = _run_fwd(hip, qkv, mask, B, S, NH, 0.0, 0, cu=cu_d, qoff=qo_d)
+    dqkv = _run_bwd(hip, qkv, mask, out, dout, lse, B, S, NH, 0.0, 0, cu=cu_d, qoff=qo_d)
+    torch.cuda.synchronize()
+    for b, (n, q) in enumerate(zip(lens, nq)):
+        lo = int(cu[b])
+        rows = slice(lo, lo + n)
+        d_lim = dout[rows].clone()
+        d_lim[q:] = 0                                      # gradient arrives at the query rows only
+        o_ref, lse_ref, g_ref = _ref(qkv[rows], mask[rows][None], 1, n, NH, d_lim)
+        assert bool((out[lo + q:lo + n] == 7.0).all())     # rows past the queries: untouched
+        assert float(dqkv[lo + q:lo + n, :H].abs().max()) == 0.0 if n > q else True
+        if q == 0:
+            assert float(dqkv[rows].abs().max()) == 0.0
+            continue
+        torch.testing.assert_close(out[lo:lo + q].float(), o_ref[:q], rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(lse[b, :, :q], lse_ref[0, :, :q], rtol=1e-4, atol=2e-3)
+        for name, sl, rr in (("dq", slice(0, H), slice(0, q)), ("dk", slice(H, 2 * H), slice(0, n)),
+                             ("dv", slice(2 * H, 3 * H), slice(0, n))):
+            if float(g_ref[rr, sl].abs().max()) == 0.0:
+                assert float(dqkv[rows][rr, sl].float().abs().max()) < 1e-3, (b, name)
+                continue
+            e = _relerr(dqkv[rows][rr, sl], g_ref[rr, sl])
+            assert e < 2e-2, (b, n, q, name, e)
+    o1, l1 = _run_fwd(hip, qkv, mask, B, S, NH, 0.2, 9, cu=cu_d, qoff=qo_d)
+    o2, _ = _run_fwd(hip, qkv, mask, B, S, NH, 0.2, 9, cu=cu_d, qoff=qo_d)
+    g1 = _run_bwd(hip, qkv, mask, o1, dout, l1, B, S, NH, 0.2, 9, cu=cu_d, qoff=qo_d)
+    g2 = _run_bwd(hip, qkv, mask, o1, dout, l1, B, S, NH, 0.2, 9, cu=cu_d, qoff=qo_d)
+    assert torch.equal(o1, o2) and torch.equal(g1, g2) and bool(torch.isfinite(g1).all())
+    with pytest.raises(hip.StonkHipError):                 # query limits need the packed layout
+        _run_fwd(hip, qkv[:512], torch.ones(1, 512, dtype=torch.long, device="cuda"), 1, 512, NH, qoff=qo_d)
 
 
 def test_attention_packed_equals_padded_when_nothing_is_dropped(hip):

@@ -110,9 +110,10 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert lib.stonk_gemm_nt_bf16(0, 0, 0, 0, 0, 0, 1, 128, 64, 0, 0, 0, 0, 0, 0, 1.0, 1, 0, 0, 0.0, 0, 0, 0) == -1
     assert lib.stonk_gemm_nt_bf16(16, 64, 16, 64, 16, 128, 1, 128, 64, 0, 0, 0, 0, 0, 0, 1.0, 1, 0, 0, 0.0, 0, 9, 0) == -1   # unknown kernel
     assert lib.stonk_layernorm_fwd(16, 16, 16, 16, 0, 0, 4, 7, 1e-12, 0, 0.0, 0, 0) == -2
-    assert lib.stonk_attention_fwd(16, 16, 16, 192, 0, 0, 16, 64, 0, 1, 1, 100, 64, 0.125, 0.0, 0, 0) == -2
-    assert lib.stonk_attention_fwd(16, 16, 16, 192, 0, 0, 16, 64, 0, 1, 1, 4224, 64, 0.125, 0.0, 0, 0) == -2    # > 4096 keys: refused
-    assert lib.stonk_attention_fwd(16, 16, 16, 192, 0, 16, 16, 64, 0, 1, 1, 512, 64, 0.125, 0.0, 0, 0) == -1  # packed rows need a mask
+    assert lib.stonk_attention_fwd(16, 16, 16, 192, 0, 0, 0, 16, 64, 0, 1, 1, 100, 64, 0.125, 0.0, 0, 0) == -2
+    assert lib.stonk_attention_fwd(16, 16, 16, 192, 0, 0, 0, 16, 64, 0, 1, 1, 4224, 64, 0.125, 0.0, 0, 0) == -2    # > 4096 keys: refused
+    assert lib.stonk_attention_fwd(16, 16, 16, 192, 0, 16, 0, 16, 64, 0, 1, 1, 512, 64, 0.125, 0.0, 0, 0) == -1
+    assert lib.stonk_attention_fwd(16, 16, 16, 192, 16, 0, 16, 16, 64, 0, 1, 1, 512, 64, 0.125, 0.0, 0, 0) == -1  # query limits need the packed layout  # packed rows need a mask
     with pytest.raises(_hip.StonkHipError):
         _hip.check(-2, "x")
 
@@ -290,7 +291,8 @@ def test_embedding_row_builder_matches_the_reference():
 
 def test_unpad_plan_restatement_keeps_exactly_what_the_loss_reads():
     """oracle/masking_oracle.unpad_plan (the checker of csrc/unpad.hip): live keys, labelled positions and position 0 are
-    kept in position order, nothing else; a sequence without live keys keeps everything; the maps invert each other."""
+    kept, nothing else - a sequence's READ rows (labelled + position 0) first, then its other rows, each group in position
+    order; a sequence without live keys keeps everything; the maps invert each other."""
     import numpy as np
 
     from oracle import masking_oracle as mo
@@ -304,14 +306,19 @@ def test_unpad_plan_restatement_keeps_exactly_what_the_loss_reads():
     tl = np.full((B, half), -100)
     el = np.full((B, half), -100)
     tl[0, 5] = 17                   # a labelled padding position
-    rop, por, cu, rm = mo.unpad_plan(am, tl, el)
-    kept0 = [0, 1, 2, 5] + list(range(half, S))
-    assert cu.tolist() == [0, len(kept0), len(kept0) + S, len(kept0) + 2 * S, len(kept0) + 3 * S]
-    assert por[:len(kept0)].tolist() == kept0 and rop[3] == -1 and rop[5] == 3
-    assert rm[:len(kept0)].tolist() == [1, 1, 1, 0] + [1] * half            # the labelled pad row is a query, never a key
+    el[0, 2] = 4                    # a labelled entity position (s = 10)
+    rop, por, cu, rm, rr, rofp, ro = mo.unpad_plan(am, tl, el, read=True)
+    order0 = [0, 5, 10] + [1, 2] + [8, 9] + list(range(11, S))       # read rows first, then the other kept rows
+    assert cu.tolist() == [0, len(order0), len(order0) + S, len(order0) + 2 * S, len(order0) + 3 * S]
+    assert por[:len(order0)].tolist() == order0 and rop[3] == -1 and rop[5] == 1 and rop[1] == 3
+    assert rm[:len(order0)].tolist() == [1, 0, 1] + [1] * (len(order0) - 3)   # the labelled pad row is a query, never a key
     total = int(cu[-1])
     assert (rop[por[:total]] == np.arange(total)).all() and (por[total:] == -1).all()
     assert rm[cu[2]] == 0 and rop[2 * S] == cu[2]
+    assert ro.tolist() == [0, 3, 4, 5, 6] and rr[:6].tolist() == [0, 1, 2, cu[1], cu[2], cu[3]]
+    assert rofp[5] == 1 and rofp[10] == 2 and rofp[1] == -1 and (rr[6:] == -1).all()
+    for b in range(B):                                                  # a sequence's read rows are its first rows
+        assert (rr[ro[b]:ro[b + 1]] == cu[b] + np.arange(ro[b + 1] - ro[b])).all()
 
 
 def test_asan_host_build_of_the_launchers():

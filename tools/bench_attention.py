@@ -25,12 +25,12 @@ p, seed = float(os.environ.get("P", 0.1)), 3
 
 
 def fwd():
-    hip.call("stonk_attention_fwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask), 0,
+    hip.call("stonk_attention_fwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask), 0, 0,
              hip.ptr(out), H, hip.ptr(lse), B, NH, S, 64, 0.125, p, seed, hip.stream_ptr())
 
 
 def bwd(name):
-    hip.call(name, hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask), 0, hip.ptr(out), H,
+    hip.call(name, hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask), 0, 0, hip.ptr(out), H,
              hip.ptr(dout), H, hip.ptr(lse), hip.ptr(delta), hip.ptr(dqkv), hip.ptr(dqkv) + 2 * H, 3 * H,
              hip.ptr(dqkv) + 4 * H, B, NH, S, 64, 0.125, p, seed, hip.stream_ptr())
 

@@ -110,13 +110,13 @@ def bench_attn():
     for p in (0.0, 0.1):
         def f():
             hip.call("stonk_attention_fwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H,
-                     hip.ptr(mask), 0, hip.ptr(out), H, hip.ptr(lse), B, NH, S, 64, 0.125, p, 1, hip.stream_ptr())
+                     hip.ptr(mask), 0, 0, hip.ptr(out), H, hip.ptr(lse), B, NH, S, 64, 0.125, p, 1, hip.stream_ptr())
         t = timeit(f)
         fl = 4.0 * B * NH * S * S * 64
         print(f"attn_fwd B{B} S{S} NH{NH} p={p}: {t*1e6:.1f} us  {fl/t/1e12:.1f} TF/s", flush=True)
         def g():
             hip.call("stonk_attention_bwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H,
-                     hip.ptr(mask), 0, hip.ptr(out), H, hip.ptr(dout), H, hip.ptr(lse), hip.ptr(delta), hip.ptr(dqkv),
+                     hip.ptr(mask), 0, 0, hip.ptr(out), H, hip.ptr(dout), H, hip.ptr(lse), hip.ptr(delta), hip.ptr(dqkv),
                      hip.ptr(dqkv) + 2 * H, 3 * H, hip.ptr(dqkv) + 4 * H, B, NH, S, 64, 0.125, p, 1, hip.stream_ptr())
         t = timeit(g)
         print(f"attn_bwd B{B} S{S} NH{NH} p={p}: {t*1e6:.1f} us  {2.5*fl/t/1e12:.1f} TF/s (algorithmic 10*B*NH*S^2*D)",

@@ -20,9 +20,9 @@ delta = torch.empty(B, NH, S, device="cuda")
 dqkv = torch.empty_like(qkv)
 for p in (0.0, 0.1):
     for _ in range(3):
-        hip.call("stonk_attention_fwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask), 0,
+        hip.call("stonk_attention_fwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask), 0, 0,
                  hip.ptr(out), H, hip.ptr(lse), B, NH, S, 64, 0.125, p, 1, hip.stream_ptr())
-        hip.call("stonk_attention_bwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask), 0,
+        hip.call("stonk_attention_bwd", hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask), 0, 0,
                  hip.ptr(out), H, hip.ptr(dout), H, hip.ptr(lse), hip.ptr(delta), hip.ptr(dqkv), hip.ptr(dqkv) + 2 * H,
                  3 * H, hip.ptr(dqkv) + 4 * H, B, NH, S, 64, 0.125, p, 1, hip.stream_ptr())
     torch.cuda.synchronize()

@@ -534,7 +534,14 @@ class Engine:
         self._pref_par ^= 1
         out = self.buf(f"bb.pref{self._pref_par}", (B * half, H))
         with torch.cuda.stream(self._bb_stream):
-            x = self.backbone_fwd(input_ids, S, B, half, training)
+            # dropout masks are a function of (step counter, layer, site, element): the prefetched forward draws the masks
+            # of the step that will CONSUME it (the counter advances once per encode), so a run that prefetches and one
+            # that does not - or a resumed one - see the same masks
+            self.seed_base += 1
+            try:
+                x = self.backbone_fwd(input_ids, S, B, half, training)
+            finally:
+                self.seed_base -= 1
             out.copy_(x)
             done = torch.cuda.Event()
             done.record()

@@ -76,16 +76,19 @@ def executed_fraction(rows_executed):
     unpadded encoder actually ran, and the share of rows the LAST layer's feed-forward block, the pooler and the head
     transform ran on (Engine.rows_executed)."""
     r = rows_executed
-    return (r[0] / r[1], r[3] / r[4], r[5] / r[1]) if r[1] else (1.0, 1.0, 1.0)
+    return (r[0] / r[1], r[3] / r[4], r[5] / r[1], r[6] / r[4]) if r[1] else (1.0, 1.0, 1.0, 1.0)
 
 
-def gflop_per_pair_executed(cfg, lin: float, att: float, rdf: float) -> dict:
+def gflop_per_pair_executed(cfg, lin: float, att: float, rdf: float, att_last: float = None) -> dict:
     """gflop_per_pair / encoder_gflop_per_pair with the trainable encoder's and the head transform's terms scaled to the
     rows that ran (frozen backbone and label-sparse decoders are unaffected)."""
     H, I, L, S = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.max_position_embeddings
     half = S // 2
     proj, ffn, attn = 2 * S * 4 * H * H, 2 * S * 2 * H * I, 4 * S * S * H
-    enc = 3 * ((L - 1) * (lin * (proj + ffn) + att * attn) + lin * proj + rdf * ffn + att * attn)
+    att_last = att if att_last is None else att_last
+    pruned_attn = att_last < att          # the last layer's output projection then runs on the read rows as well
+    last_proj = lin * proj * 0.75 + (rdf if pruned_attn else lin) * proj * 0.25    # QKV on every row | output projection
+    enc = 3 * ((L - 1) * (lin * (proj + ffn) + att * attn) + last_proj + rdf * ffn + att_last * attn)
     bb = L * (2 * half * (4 * H * H + 2 * H * I) + 4 * half * half * H)
     lab = int(half * 0.15)
     heads = rdf * 3 * 2 * S * H * H + 3 * 2 * lab * H * (cfg.vocab_size + cfg.kg_vocab_size)
@@ -330,8 +333,8 @@ def main():
         # and backward (the backward span ends once that span's weight gradients on the second stream are done; the
         # decoders' weight gradients still running on that stream at its start are inside it, so this errs low)
         enc_s = (timer.span_seconds("encoder_fwd") + timer.span_seconds("encoder_bwd")) / 2
-        lin, att, rdf = executed_fraction(model.engine.rows_executed)
-        enc_gf = gflop_per_pair_executed(cfg, lin, att, rdf)["encoder"]
+        lin, att, rdf, att_last = executed_fraction(model.engine.rows_executed)
+        enc_gf = gflop_per_pair_executed(cfg, lin, att, rdf, att_last)["encoder"]
         enc_tf = enc_gf * args.batch / 1e3 / enc_s
         encoder_path = {"what": "trainable encoder forward + backward (QKV, attention, projections, FFN, LayerNorm, "
                                 "weight gradients), event spans on the main stream over two instrumented steps; FLOPs of "
@@ -345,8 +348,8 @@ def main():
     if rank == 0:
         pairs = args.batch * world * args.steps
         value = pairs / dt
-        lin, att, rdf = executed_fraction(model.engine.rows_executed)
-        gfl = gflop_per_pair_executed(cfg, lin, att, rdf)["step"]   # the FLOPs the step executed
+        lin, att, rdf, att_last = executed_fraction(model.engine.rows_executed)
+        gfl = gflop_per_pair_executed(cfg, lin, att, rdf, att_last)["step"]   # the FLOPs the step executed
         out = {"metric": "text-triple pairs/sec (whole node), seq_len=512 hidden=768, 1/2/4/8 MI355X", "value": round(value, 2),
                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
@@ -357,6 +360,7 @@ def main():
                "final_loss": round(final_loss, 4),
                "gflop_per_pair": round(gfl, 1), "gflop_per_pair_padded": round(gflop_per_pair(cfg), 1),
                "rows_executed": {"linear": round(lin, 4), "attention": round(att, 4), "last_ffn_and_heads": round(rdf, 4),
+                                 "last_attention": round(att_last, 4),
                                  "what": "share of the padded encoder's rows (and of its rows^2 per sequence) the unpadded "
                                          "encoder ran: positions that are neither live keys, nor labelled, nor position 0 "
                                          "are dropped - no loss term or gradient reads them; the last layer's feed-forward "

@@ -119,7 +119,9 @@ class Engine:
         self._pref_par = 0
         # what ran: [rows, padded rows they stand for, encoder passes, sum over sequences of rows^2, of S^2] - bench.py prices
         # the step on the FLOPs actually executed (linear layers ~ rows, attention ~ rows^2 per sequence)
-        self.rows_executed = [0, 0, 0, 0, 0, 0]   # (last: rows of the last layer's feed-forward block / pooler / head)
+        # (sixth: rows of the last layer's feed-forward block / pooler / head; seventh: query rows x key rows of the last
+        # layer's attention, summed over sequences)
+        self.rows_executed = [0, 0, 0, 0, 0, 0, 0]
         self._plan_host: Optional[torch.Tensor] = None
         self._wstream: Optional[torch.cuda.Stream] = None
         # The optimizer (grad-norm, AdamW, W^T refresh: ~2 ms of HBM-bound work) runs on a third stream; the next step's
@@ -643,7 +645,10 @@ class Engine:
         else:
             sq = B * S * S
         Th = T if rd is None else rd["T"]          # rows of the sequence output (and of everything the heads run on)
-        for i, v in enumerate((T, cap, 1, sq, B * S * S, Th)):
+        sq_last = sq
+        if rd is not None and rd["attn"]:
+            sq_last = sum((host[B + 2 + i] - host[B + 1 + i]) * (offs[i + 1] - offs[i]) for i in range(B))
+        for i, v in enumerate((T, cap, 1, sq, B * S * S, Th, sq_last)):
             self.rows_executed[i] += v
         # F2 gather + concat + embeddings LayerNorm
         sum0 = self.buf("e.sum0", (cap, H))

@@ -74,7 +74,7 @@ def test_unpadded_step_equals_padded_step(hip):
                         {k: v.detach().clone() for k, v in m.named_grad_views().items()}, list(m.engine.rows_executed)))
         (l0, t0, g0, r0), (l1, t1, g1, r1), (l2, t2, g2, r2), (l3, t3, g3, r3) = res
         # ... and the last layer's attention block behind the QKV projection on the read rows too (query limits)
-        assert r3 == r2 and abs(l0 - l3) < 1e-4 * abs(l0) and np.allclose(t0, t3, rtol=2e-4, atol=1e-5)
+        assert r3[:6] == r2[:6] and r3[6] < r2[6] // 2 and abs(l0 - l3) < 1e-4 * abs(l0) and np.allclose(t0, t3, rtol=2e-4, atol=1e-5)
         errs3 = sorted(((_rel(g3[k], g0[k]), k) for k in g0), reverse=True)
         print("pruned last layer (attention too) vs padded, worst gradient tensors:", [(round(e, 5), k) for e, k in errs3[:3]])
         assert errs3[0][0] < 1e-2 and errs3[len(errs3) // 2][0] < 2e-3, errs3[:3]

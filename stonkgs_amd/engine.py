@@ -129,7 +129,6 @@ class Engine:
         # stream after the last parameter write - called before the first trainable weight is read and by every accessor.
         self._opt_stream: Optional[torch.cuda.Stream] = None
         self._params_ready: Optional[torch.cuda.Event] = None
-        self._encoder_params_ready: Optional[torch.cuda.Event] = None
         self._wgrad_done: Dict[int, torch.cuda.Event] = {}   # layer parity -> side-stream event after its last wgrad
         self._wt_desc = None   # (device table, entries, tiles) of the batched W^T refresh
         # development switches, read ONCE here: the 128x128 weight-gradient kernel everywhere / the CU share of the
@@ -162,7 +161,6 @@ class Engine:
             return
         if self._opt_stream is None:
             self._opt_stream = torch.cuda.Stream(device=self.device)
-        self._encoder_params_ready = None
         self._opt_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._opt_stream):
             yield
@@ -186,22 +184,6 @@ class Engine:
         """Order the current stream after the last optimizer step, if it ran on the optimizer stream (no host
         synchronisation). The event is kept until the next step replaces it: callers on different streams each wait."""
         ev = self._params_ready
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-
-    def mark_encoder_params_ready(self) -> None:
-        """Called by the optimizer (on its stream) once everything the ENCODER forward reads is final: the optimizer
-        updates the encoder's slice of the flat buffers first and the two decoder matrices - 64 % of the parameters, read
-        only at the end of a forward - last, so that the next step's encoder forward starts a millisecond of HBM-bound
-        AdamW earlier and runs beside the rest of it."""
-        ev = torch.cuda.Event()
-        ev.record()
-        self._encoder_params_ready = ev
-
-    def wait_encoder_params(self) -> None:
-        """Order the current stream after the optimizer's update of everything but the decoder matrices (or after the
-        whole step, when the optimizer made no such cut)."""
-        ev = self._encoder_params_ready or self._params_ready
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
@@ -647,7 +629,7 @@ class Engine:
             if hint is not None and hit:
                 self.prefetch_backbone(hint, training)
                 hint = None
-        self.wait_encoder_params()   # everything above read frozen weights only; from here on the trainable encoder's
+        self.wait_params()   # everything above read frozen weights only; from here on the trainable ones
         T, rows, cu, mask, rd = cap, cap, None, attention_mask, None
         if plan is not None:
             ev.synchronize()                       # (the backbone's launches are queued: the GPU is not waiting for us)
@@ -729,7 +711,6 @@ class Engine:
                                       (mlm_labels, ent_labels) if packed else None)
         T, plan = save["Th"], save["plan"]          # rows of the sequence output: all packed rows, or the read rows
         row_of_pos = save["head_map"]
-        self.wait_params()                          # the decoder matrices: the optimizer updates them last
         nsp = self.buf("h.nsp", (B, 2), F32)
         hip.call("stonk_small_linear_fwd", pooled.data_ptr(), H, f("cls.seq_relationship.weight").data_ptr(),
                  f("cls.seq_relationship.bias").data_ptr(), nsp.data_ptr(), B, 2, H, hip.SMALL_X_F32, st)

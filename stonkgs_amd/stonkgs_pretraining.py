@@ -48,9 +48,6 @@ class TrainingArguments:
     # clip + AdamW + W^T refresh (and the tail of the gradient all-reduce) on their own stream, beside the next step's
     # frozen-backbone forward; parameters read through the model's accessors or after torch.cuda.synchronize() are final
     optimizer_overlap: bool = True
-    # ... and update the encoder's part of the flat buffers before the two decoder matrices (64 % of the parameters, read
-    # only at the end of a forward): the next step's encoder forward then waits for the first part only
-    optimizer_encoder_first: bool = True
     # queue the NEXT batch's frozen-backbone forward beside the current step's encoder forward (it depends on token ids and
     # frozen weights only); needs the next batch: `Trainer.train` peeks it, `training_step(..., next_inputs=)` takes it
     prefetch_backbone: bool = True
@@ -126,27 +123,19 @@ class FusedAdamW:
             self._decay_spans = torch.tensor(rows, dtype=torch.int64, device=s.data.device).reshape(-1, 2)
         return self._decay_spans
 
-    def apply_update(self, lr: float, grad_scale: float = 1.0, encoder_first: Optional[int] = None,
-                     after_encoder: Optional[Callable[[], None]] = None) -> None:
+    def apply_update(self, lr: float, grad_scale: float = 1.0) -> None:
         """clip (from gnorm_sq) + AdamW + bf16 mirror + gradient zeroing over this rank's pieces. Decoupled weight decay
         (p *= 1 - lr * wd on the decayed tensors only: torch.optim.AdamW's order) happens inside the same kernel, from a
-        device table of the decayed tensors' spans. `encoder_first` (replicated optimizer only): offset at which the flat
-        buffer's encoder part begins - it is updated FIRST, `after_encoder()` is called (the engine records an event the
-        next forward's encoder waits for), then the decoder matrices in front of it."""
+        device table of the decayed tensors' spans."""
         s, st = self.store, hip.stream_ptr()
         b1, b2 = self.betas
         wd = float(self.weight_decay)
         tab = self._decay_table() if wd else None
-        pieces = self._pieces()
-        if self.spans is None and encoder_first:
-            pieces = [(encoder_first, encoder_first, s.numel - encoder_first), (0, 0, encoder_first)]
-        for i, (off, soff, n) in enumerate(pieces):
+        for off, soff, n in self._pieces():
             hip.call("stonk_adamw_step", s.data.data_ptr() + 4 * off, s.grad.data_ptr() + 4 * off,
                      self.m.data_ptr() + 4 * soff, self.v.data_ptr() + 4 * soff, s.bf16.data_ptr() + 2 * off, n, lr, b1, b2,
                      self.eps, wd, 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count, self.gnorm_sq.data_ptr(),
                      self.max_grad_norm, grad_scale, hip.ptr(tab), 0 if tab is None else tab.shape[0], off, st)
-            if i == 0 and after_encoder is not None and len(pieces) == 2 and self.spans is None and encoder_first:
-                after_encoder()
 
     def step(self, lr: float, grad_scale: float = 1.0) -> None:
         self.step_count += 1
@@ -339,10 +328,6 @@ class Trainer:
         self.optimizer = FusedAdamW(model._store, (self.args.adam_beta1, self.args.adam_beta2), self.args.adam_epsilon,
                                     self.args.weight_decay, self.args.max_grad_norm, spans=self.sync.owned_spans())
         model.engine.comm_overlap = self.sync.active   # (see Engine.comm_overlap)
-        # where the encoder's part of the flat buffers begins (behind the two decoder matrices: the optimizer updates it first)
-        st = model._store
-        self._encoder_offset = (st.span("cls.predictions.text_decoder.weight")[1]
-                                if "cls.predictions.text_decoder.weight" in st.index and not self.sync.shard else None)
         self.global_step = 0
         self._micro = 0
         self._next_cache = None
@@ -385,9 +370,7 @@ class Trainer:
                 opt.step_count += 1
                 opt.accumulate_grad_norm_sq()               # replicated: the whole buffer; sharded: this rank's pieces ...
                 self.sync.all_reduce_scalar(opt.gnorm_sq)   # ... summed over the ranks (a no-op when replicated)
-                cut = self.args.optimizer_overlap and self.args.optimizer_encoder_first
-                opt.apply_update(lr, grad_scale=scale, encoder_first=self._encoder_offset if cut else None,
-                                 after_encoder=model.engine.mark_encoder_params_ready if cut else None)
+                opt.apply_update(lr, grad_scale=scale)
                 if self.sync.shard:
                     model._store.grad.zero_()               # (the kernel zeroed the owned pieces only)
                     self.sync.gather_params(model._store.data)

@@ -139,6 +139,15 @@ int stonk_attention_bwd(const void* q, const void* k, const void* v, int64_t ld,
                         const float* lse, float* delta_ws, void* dq, void* dk, int64_t ldd, void* dv, int B, int NH,
                         int S, int D, float scale, float drop_p, uint32_t seed, void* stream);
 
+/* The same in separately launched parts (`phases`: STONK_ATTN_BWD_DELTA | _DQ | _DKV), so that the dQ and the dK / dV
+ * kernels - independent once delta = rowsum(dO * O) exists - can be put on two streams: run DELTA first, order the DKV
+ * call's stream after it, then DQ and DKV in any order or side by side. phases = STONK_ATTN_BWD_ALL is stonk_attention_bwd. */
+int stonk_attention_bwd_phases(int phases, const void* q, const void* k, const void* v, int64_t ld,
+                               const int64_t* attention_mask, const int* seq_offsets, const int* q_offsets, const void* out,
+                               int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta_ws, void* dq,
+                               void* dk, int64_t ldd, void* dv, int B, int NH, int S, int D, float scale, float drop_p,
+                               uint32_t seed, void* stream);
+
 /* out[c][r] = in[r][c] (bf16). Rows >= *rows_dev (nullable) read as zero; colsum (nullable, fp32) += column sums
  * of `in` (bias gradients). Feeds wgrad operands to stonk_gemm_nt_bf16. */
 int stonk_transpose_bf16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int64_t rows, int cols,

@@ -30,6 +30,7 @@ LN_DROPOUT = 1 << 0
 SMALL_TANH = 1
 SMALL_X_F32 = 16
 LOSS_MSE, LOSS_MSE_BROADCAST, LOSS_BCE = 0, 1, 2
+ATTN_BWD_DELTA, ATTN_BWD_DQ, ATTN_BWD_DKV, ATTN_BWD_ALL = 1, 2, 4, 7
 
 _vp, _i32, _i64, _f32, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 
@@ -50,6 +51,8 @@ _SIGNATURES = {
     "stonk_attention_fwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _u32, _vp],
     "stonk_attention_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i32,
                             _i32, _i32, _i32, _f32, _f32, _u32, _vp],
+    "stonk_attention_bwd_phases": [_i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp,
+                                   _i32, _i32, _i32, _i32, _f32, _f32, _u32, _vp],
     "stonk_transpose_bf16": [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp],
     "stonk_transpose_f32_to_bf16": [_vp, _vp, _i64, _i32, _i64, _vp],
     "stonk_transpose_bf16_batched": [_vp, _i32, _i32, _vp],

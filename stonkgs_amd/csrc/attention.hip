@@ -39,6 +39,7 @@ struct AttnArgs {
   const long* mask;   // [B,S] or null; with `cu`: one word per ROW of the packed layout (required)
   const int* cu;      // null, or [B+1] row offsets: sequence b = rows cu[b] .. cu[b+1]-1 of q/k/v/out/dout/dq/dk/dv (<= S rows)
   const int* qoff;    // null, or [B+1]: only the first qoff[b+1] - qoff[b] rows of sequence b are QUERIES (keys: all of them)
+  int dq_writes_delta;   // the dQ kernel stores delta (default); 0 when attn_delta_kernel has, and dK/dV may be reading it
   bf16* out;          // fwd: context [T, ldo]; bwd: the forward's context (read)
   long ldo;
   float* lse;         // [B, NH, S] natural-log LSE of the scaled+masked scores
@@ -422,6 +423,28 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
   if (hh == 0 && p.lse) p.lse[(long)(b * p.NH + h) * S + q0 + r] = (m + __builtin_amdgcn_logf(l)) * LN2;
 }
 
+// ------------------------------------------------------------------ backward: delta = rowsum(dO * O) on its own
+// (what lets the dQ and the dK/dV kernels run side by side on two streams: the dQ kernel otherwise produces it)
+__global__ __launch_bounds__(128) void attn_delta_kernel(const AttnArgs p) {
+  const AttnBlock blk = attn_block();
+  const int b = blk.b, h = blk.h;
+  const int S = p.S;
+  SEQ_EXTENT();
+  QUERY_EXTENT();
+  const int q = blk.xb * 128 + threadIdx.x;
+  if (q >= nq) return;
+  const bf16* drow = p.dout + (tok0 + q) * p.lddo + h * HD;
+  const bf16* orow = p.out + (tok0 + q) * p.ldo + h * HD;
+  float dlt = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const bf16x8 d = *(const bf16x8*)(drow + 8 * c), o = *(const bf16x8*)(orow + 8 * c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dlt += (float)o[j] * (float)d[j];
+  }
+  p.delta[(long)(b * p.NH + h) * S + q] = dlt;
+}
+
 // ------------------------------------------------------------------ backward: dQ (query on the lane)
 // Also produces delta = rowsum(dO * O) for its query rows (the dK/dV kernel, launched after it, reads it).
 template <bool HAS_MASK, bool DROPOUT>
@@ -458,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   }
   dlt += __shfl_xor(dlt, 32, 64);
   const long stat = (long)(b * p.NH + h) * S + q0 + r;
-  if (hh == 0 && qlive) p.delta[stat] = dlt;
+  if (hh == 0 && qlive && p.dq_writes_delta) p.delta[stat] = dlt;
   const float lse_q = p.lse[stat - (q0 + r) + qr];
   // dS = P * (drop(dP) - delta) with drop(dP) = keep ? dP / (1-p) : 0  ==  (1/(1-p)) * P * ((keep ? dP : 0) - (1-p) delta)
   const float dlt_s = DROPOUT ? dlt / p.drop_scale : dlt;
@@ -775,12 +798,11 @@ extern "C" int stonk_attention_fwd(const void* q, const void* k, const void* v, 
   return stonk_launch_status();
 }
 
-extern "C" int stonk_attention_bwd(const void* q, const void* k, const void* v, int64_t ld,
-                                   const int64_t* attention_mask, const int* seq_offsets, const int* q_offsets,
-                                   const void* out, int64_t ldo, const void* dout,
-                                   int64_t lddo, const float* lse, float* delta_ws, void* dq, void* dk, int64_t ldd,
-                                   void* dv, int B, int NH, int S, int D, float scale, float drop_p, uint32_t seed,
-                                   void* stream) {
+static int attention_bwd_launch(int phases, const void* q, const void* k, const void* v, int64_t ld,
+                                const int64_t* attention_mask, const int* seq_offsets, const int* q_offsets, const void* out,
+                                int64_t ldo, const void* dout, int64_t lddo, const float* lse, float* delta_ws, void* dq,
+                                void* dk, int64_t ldd, void* dv, int B, int NH, int S, int D, float scale, float drop_p,
+                                uint32_t seed, void* stream) {
   int rc = check_common(q, k, v, ld, B, NH, S, D);
   if (rc) return rc;
   STONK_CHECK_ARG(out && dout && lse && delta_ws && dq && dk && dv, STONK_EINVAL);
@@ -796,13 +818,16 @@ extern "C" int stonk_attention_bwd(const void* q, const void* k, const void* v, 
   a.dq = (bf16*)dq; a.dk = (bf16*)dk; a.dv = (bf16*)dv; a.ldd = ldd;
   a.B = B; a.NH = NH; a.S = S; a.scale = scale;
   a.drop_thr32 = stonk_drop_thr32(drop_p); a.drop_scale = 1.f / (1.f - drop_p); a.seed = stonk_seed_mix(seed);
+  a.dq_writes_delta = phases == STONK_ATTN_BWD_ALL;   // (split calls: the DELTA phase produces it, before DQ and DKV)
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(S / 128, NH, B), block(256);
   const bool hm = attention_mask != nullptr, dr = drop_p > 0.f;
-#define LAUNCH_BWD(HM, DR)                                                                  \
-  do {                                                                                      \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HM, DR>), grid, block, 0, st, a);                \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HM, DR>), grid, block, 0, st, a);               \
+  if ((phases & STONK_ATTN_BWD_DELTA) && phases != STONK_ATTN_BWD_ALL)
+    hipLaunchKernelGGL(attn_delta_kernel, grid, dim3(128), 0, st, a);
+#define LAUNCH_BWD(HM, DR)                                                                                         \
+  do {                                                                                                             \
+    if (phases & STONK_ATTN_BWD_DQ) hipLaunchKernelGGL((attn_bwd_dq_kernel<HM, DR>), grid, block, 0, st, a);       \
+    if (phases & STONK_ATTN_BWD_DKV) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HM, DR>), grid, block, 0, st, a);     \
   } while (0)
   if (hm && dr) LAUNCH_BWD(true, true);
   else if (hm) LAUNCH_BWD(true, false);
@@ -810,4 +835,24 @@ extern "C" int stonk_attention_bwd(const void* q, const void* k, const void* v, 
   else LAUNCH_BWD(false, false);
 #undef LAUNCH_BWD
   return stonk_launch_status();
+}
+
+extern "C" int stonk_attention_bwd(const void* q, const void* k, const void* v, int64_t ld,
+                                   const int64_t* attention_mask, const int* seq_offsets, const int* q_offsets,
+                                   const void* out, int64_t ldo, const void* dout,
+                                   int64_t lddo, const float* lse, float* delta_ws, void* dq, void* dk, int64_t ldd,
+                                   void* dv, int B, int NH, int S, int D, float scale, float drop_p, uint32_t seed,
+                                   void* stream) {
+  return attention_bwd_launch(STONK_ATTN_BWD_ALL, q, k, v, ld, attention_mask, seq_offsets, q_offsets, out, ldo, dout, lddo,
+                              lse, delta_ws, dq, dk, ldd, dv, B, NH, S, D, scale, drop_p, seed, stream);
+}
+
+extern "C" int stonk_attention_bwd_phases(int phases, const void* q, const void* k, const void* v, int64_t ld,
+                                          const int64_t* attention_mask, const int* seq_offsets, const int* q_offsets,
+                                          const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
+                                          float* delta_ws, void* dq, void* dk, int64_t ldd, void* dv, int B, int NH, int S,
+                                          int D, float scale, float drop_p, uint32_t seed, void* stream) {
+  STONK_CHECK_ARG(phases > 0 && phases <= STONK_ATTN_BWD_ALL, STONK_EINVAL);
+  return attention_bwd_launch(phases, q, k, v, ld, attention_mask, seq_offsets, q_offsets, out, ldo, dout, lddo, lse,
+                              delta_ws, dq, dk, ldd, dv, B, NH, S, D, scale, drop_p, seed, stream);
 }

@@ -39,3 +39,8 @@
 #define STONK_LOSS_MSE 0            /* regression: MSELoss over [B,C] */
 #define STONK_LOSS_MSE_BROADCAST 1  /* regression with num_labels = 1 and 1-D labels: torch's [B,1] x [B] -> [B,B] broadcast */
 #define STONK_LOSS_BCE 2            /* multi-label: BCEWithLogitsLoss over [B,C] */
+// --- stonk_attention_bwd_phases `phases`: which kernels of the attention backward a call launches ---
+#define STONK_ATTN_BWD_DELTA 1 /* delta = rowsum(dO * O) by a kernel of its own: must have completed before DKV starts */
+#define STONK_ATTN_BWD_DQ 2    /* dQ (stores delta itself only in the ALL form) */
+#define STONK_ATTN_BWD_DKV 4   /* dK, dV (reads delta) */
+#define STONK_ATTN_BWD_ALL 7   /* = stonk_attention_bwd: dQ (producing delta), then dK / dV, on one stream */

@@ -110,6 +110,10 @@ class Engine:
         # rows first, the attention kernels compute the first rows of every sequence as queries only (`q_offsets`; keys and
         # values: every row), and the output projection + LayerNorm run on the gathered read rows.
         self.prune_last_attn = True
+        # attention backward: the dQ and the dK / dV kernels on two streams (both are VALU-bound at two or three waves per
+        # SIMD; side by side a CU hosts waves of both and its issue slots fill), delta by a small kernel in front of them
+        self.attn_bwd_two_streams = True
+        self._astream: Optional[torch.cuda.Stream] = None
         # The frozen backbone's forward depends on the batch's token ids and on frozen weights only: given a hint of the NEXT
         # batch (`next_input_ids`, set by the trainer) it is queued on a stream of its own at the start of the current step and
         # runs beside the current step's encoder forward, where no weight-gradient stream competes for the CUs.
@@ -484,11 +488,25 @@ class Engine:
             # the rows between the last sequence and T are not the attention kernel's to write, and the weight gradient
             # below contracts over all T rows: what an earlier step left there must not reach dW
             dqkv[rows:T].zero_()
-        hip.call("stonk_attention_bwd", qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H,
-                 hip.ptr(mask), hip.ptr(cu), hip.ptr(qoff), sv["ctx"].data_ptr(), H, dctx.data_ptr(), H, sv["lse"].data_ptr(),
-                 delta.data_ptr(),
+        aargs = (qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, hip.ptr(mask), hip.ptr(cu),
+                 hip.ptr(qoff), sv["ctx"].data_ptr(), H, dctx.data_ptr(), H, sv["lse"].data_ptr(), delta.data_ptr(),
                  dqkv.data_ptr(), dqkv.data_ptr() + 2 * H, 3 * H, dqkv.data_ptr() + 4 * H, B, NH, seq, 64,
-                 1.0 / math.sqrt(64.0), p_att, self.seed(lidx, 1), st)
+                 1.0 / math.sqrt(64.0), p_att, self.seed(lidx, 1))
+        if not self.attn_bwd_two_streams:
+            hip.call("stonk_attention_bwd", *aargs, st)
+        else:
+            if self._astream is None:
+                self._astream = torch.cuda.Stream(device=self.device)
+            hip.call("stonk_attention_bwd_phases", hip.ATTN_BWD_DELTA, *aargs, st)
+            fork = torch.cuda.Event()
+            fork.record()
+            self._astream.wait_event(fork)
+            with torch.cuda.stream(self._astream):
+                hip.call("stonk_attention_bwd_phases", hip.ATTN_BWD_DKV, *aargs, hip.stream_ptr())
+                join = torch.cuda.Event()
+                join.record()
+            hip.call("stonk_attention_bwd_phases", hip.ATTN_BWD_DQ, *aargs, st)
+            torch.cuda.current_stream().wait_event(join)
         # ---- QKV projection
         self.wgrad(dqkv, sv["x"], g_(prefix + ".attention.self.qkv.weight"), g_(prefix + ".attention.self.qkv.bias"),
                    3 * H, H, T)

@@ -352,6 +352,41 @@ def test_attention_query_limits(hip):
         _run_fwd(hip, qkv[:512], torch.ones(1, 512, dtype=torch.long, device="cuda"), 1, 512, NH, qoff=qo_d)
 
 
+def test_attention_backward_in_phases_equals_the_single_call(hip):
+    """stonk_attention_bwd_phases: delta by its own kernel, then dQ and dK / dV as separate launches (the engine puts them on
+    two streams) - bitwise the single call's result, padded and packed with query limits, with dropout."""
+    B, S, NH = 3, 256, 2
+    H = NH * 64
+    qkv, dout, mask = _inputs(B, S, NH, 23, True)
+    out, lse = _run_fwd(hip, qkv, mask, B, S, NH, 0.1, 4)
+    ref = _run_bwd(hip, qkv, mask, out, dout, lse, B, S, NH, 0.1, 4)
+
+    def phased(mask_, cu, qoff, out_, lse_):
+        dqkv = torch.zeros_like(qkv)
+        delta = torch.full((B, NH, S), float("nan"), device="cuda")
+        side = torch.cuda.Stream()
+        args = (hip.ptr(qkv), hip.ptr(qkv) + 2 * H, hip.ptr(qkv) + 4 * H, 3 * H, hip.ptr(mask_), hip.ptr(cu), hip.ptr(qoff),
+                hip.ptr(out_), H, hip.ptr(dout), H, hip.ptr(lse_), hip.ptr(delta), hip.ptr(dqkv), hip.ptr(dqkv) + 2 * H, 3 * H,
+                hip.ptr(dqkv) + 4 * H, B, NH, S, 64, 0.125, 0.1, 4)
+        hip.call("stonk_attention_bwd_phases", hip.ATTN_BWD_DELTA, *args, hip.stream_ptr())
+        ev = torch.cuda.Event()
+        ev.record()
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            hip.call("stonk_attention_bwd_phases", hip.ATTN_BWD_DKV, *args, hip.stream_ptr())
+        hip.call("stonk_attention_bwd_phases", hip.ATTN_BWD_DQ, *args, hip.stream_ptr())
+        torch.cuda.synchronize()
+        return dqkv
+
+    assert torch.equal(phased(mask, None, None, out, lse), ref)
+    cu = (torch.arange(B + 1, dtype=torch.int32) * S).cuda()
+    qo = torch.tensor([0, 70, 70 + 256, 70 + 256 + 1], dtype=torch.int32).cuda()
+    o2, l2 = _run_fwd(hip, qkv, mask.view(-1), B, S, NH, 0.1, 4, cu=cu, qoff=qo)
+    ref2 = _run_bwd(hip, qkv, mask.view(-1), o2, dout, l2, B, S, NH, 0.1, 4, cu=cu, qoff=qo)
+    assert torch.equal(phased(mask.view(-1), cu, qo, o2, l2), ref2)
+    assert hip.lib().stonk_attention_bwd_phases(0, *([0] * 25)) == -1
+
+
 def test_attention_packed_equals_padded_when_nothing_is_dropped(hip):
     """cu = [0, S, 2S, ...] and a per-row mask is the padded layout said differently: bitwise the same results."""
     B, S, NH = 3, 256, 2

@@ -110,9 +110,10 @@ class Engine:
         # rows first, the attention kernels compute the first rows of every sequence as queries only (`q_offsets`; keys and
         # values: every row), and the output projection + LayerNorm run on the gathered read rows.
         self.prune_last_attn = True
-        # attention backward: the dQ and the dK / dV kernels on two streams (both are VALU-bound at two or three waves per
-        # SIMD; side by side a CU hosts waves of both and its issue slots fill), delta by a small kernel in front of them
-        self.attn_bwd_two_streams = True
+        # attention backward with the dQ and the dK / dV kernels on two streams, delta by a small kernel in front of them
+        # (stonk_attention_bwd_phases). Measured: 30.33 against 30.05 ms per step - both kernels are VALU-bound and fill the
+        # chip on their own, side by side they only share it. Off; kept as a switch for tools/ab_step.py.
+        self.attn_bwd_two_streams = False
         self._astream: Optional[torch.cuda.Stream] = None
         # The frozen backbone's forward depends on the batch's token ids and on frozen weights only: given a hint of the NEXT
         # batch (`next_input_ids`, set by the trainer) it is queued on a stream of its own at the start of the current step and

@@ -37,6 +37,11 @@ for rnd in range(6):
                 os.environ.pop(name, None)
         elif attr.startswith("args:"):   # a TrainingArguments switch
             setattr(tr.args, attr[5:], val)
+        elif attr.startswith("int:"):   # int:NAME=VALUE - an integer engine attribute: True = VALUE, False = what it was
+            name, _, value = attr[4:].partition("=")
+            if not hasattr(model, "_ab_orig"):
+                model._ab_orig = getattr(model.engine, name)
+            setattr(model.engine, name, int(value) if val else model._ab_orig)
         elif attr.startswith("kernel:"):   # kernel:SITE=K[,SITE=K]: pin NT kernels (Engine.kernel_for) against the library's choice
             model.engine.kernel_for = ({k: int(v) for k, v in (kv.split("=") for kv in attr[7:].split(","))} if val else {})
         else:

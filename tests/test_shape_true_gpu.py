@@ -310,3 +310,47 @@ def test_config5_classification_head_on_the_12_layer_encoder(hip):
                    round(float(torch.nn.functional.cosine_similarity(a, r, dim=0)), 4), round(float(a.norm() / r.norm()), 4))
     print("config 5 gradients (relative error, cosine, norm ratio):", errs)
     assert all(e < 0.15 and c > 0.99 and abs(n - 1) < 0.03 for e, c, n in errs.values()), errs
+
+
+def test_bench_configuration_packed_step_equals_padded_step(hip):
+    """BASELINE config 2 exactly as `bench.py` runs it - 12L / 768h / 12 heads, V 28 996, K 175 094, batch 64 of 256 + 256,
+    text lengths uniform in [32, 256] - where no CPU reference finishes in test time: the size-independent property is that
+    dropping the rows nothing reads, pruning the last layer to its read rows and prefetching the backbone change NOTHING.
+    One step with the training path's defaults against one with every position computed (`unpad = False`), same weights,
+    dropout off: loss terms, the global gradient norm, the gradient norm of EVERY tensor and sampled slices of six."""
+    from stonkgs_amd.config import STonKGsConfig
+    from stonkgs_amd.data import synthetic_batch
+    from stonkgs_amd.stonkgs_model import STonKGsForPreTraining
+
+    cfg = STonKGsConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    batch = {k: v.cuda() for k, v in synthetic_batch(64, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=1234).items()}
+    res = []
+    for unpad in (True, False):
+        model = STonKGsForPreTraining(cfg, seed=0)
+        model.train()
+        model.engine.unpad = unpad
+        loss = float(model.forward_backward(batch))
+        model.engine.join_wgrad()
+        model.engine.check_errors()
+        torch.cuda.synchronize()
+        gv = model.named_grad_views()
+        norms = {k: float(v.double().norm()) for k, v in gv.items()}
+        sl = {k: gv[k].flatten()[:: max(1, gv[k].numel() // 4096)].float().cpu().clone()
+              for k in ("bert.encoder.layer.0.attention.self.query.weight", "bert.encoder.layer.11.output.dense.weight",
+                        "bert.encoder.layer.11.attention.self.key.weight", "bert.encoder.layer.6.intermediate.dense.weight",
+                        "bert.embeddings.position_embeddings.weight", "cls.predictions.entity_decoder.weight")}
+        res.append((loss, [float(t) for t in model.last_loss_terms], norms, sl, list(model.engine.rows_executed)))
+        del model
+        torch.cuda.empty_cache()
+    (l1, t1, n1, s1, r1), (l0, t0, n0, s0, r0) = res
+    assert r0[0] == r0[1] == 64 * 512 and 0.7 < r1[0] / r1[1] < 0.9 and r1[5] < r1[0] // 4       # rows dropped / pruned
+    print(f"config 2, packed vs padded: loss {l1:.5f} / {l0:.5f}, rows {r1[0]} of {r1[1]}, read rows {r1[5]}")
+    assert abs(l1 - l0) < 1e-4 * abs(l0) and max(abs(a - b) for a, b in zip(t1, t0)) < 2e-3
+    tot1, tot0 = sum(v * v for v in n1.values()) ** 0.5, sum(v * v for v in n0.values()) ** 0.5
+    assert abs(tot1 - tot0) < 1e-3 * tot0
+    worst = max(((abs(n1[k] - n0[k]) / max(n0[k], 1e-12)), k) for k in n0 if n0[k] > 1e-8)
+    print("config 2, packed vs padded: worst per-tensor gradient-norm difference", worst)
+    assert worst[0] < 2e-2, worst
+    for k in s0:
+        e = float((s1[k] - s0[k]).norm() / s0[k].norm())
+        assert e < 2e-2, (k, e)

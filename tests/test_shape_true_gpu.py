@@ -348,7 +348,12 @@ def test_bench_configuration_packed_step_equals_padded_step(hip):
     assert abs(l1 - l0) < 1e-4 * abs(l0) and max(abs(a - b) for a, b in zip(t1, t0)) < 2e-3
     tot1, tot0 = sum(v * v for v in n1.values()) ** 0.5, sum(v * v for v in n0.values()) ** 0.5
     assert abs(tot1 - tot0) < 1e-3 * tot0
-    worst = max(((abs(n1[k] - n0[k]) / max(n0[k], 1e-12)), k) for k in n0 if n0[k] > 1e-8)
+    # (the key projection's bias gradient is analytically zero - softmax ignores a per-query constant - and its computed
+    # value rounding noise: compared on the scale of its sibling, the query bias)
+    worst = max(((abs(n1[k] - n0[k]) / max(n0[k], 1e-12)), k) for k in n0 if n0[k] > 1e-8 and not k.endswith("key.bias"))
+    for k in n0:
+        if k.endswith("key.bias"):
+            assert max(n1[k], n0[k]) < 1e-2 * n0[k.replace("key.bias", "query.bias")], k
     print("config 2, packed vs padded: worst per-tensor gradient-norm difference", worst)
     assert worst[0] < 2e-2, worst
     for k in s0:

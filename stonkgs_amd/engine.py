@@ -486,10 +486,8 @@ class Engine:
         qoff = rd["offsets"] if qattn else None
         if qattn:
             dqkv[:T].zero_()   # dQ of the rows that were not queries (the kernel does not write them) feeds the projection's gradients
-        elif cu is not None and rows is not None and rows < T:
-            # the rows between the last sequence and T are not the attention kernel's to write, and the weight gradient
-            # below contracts over all T rows: what an earlier step left there must not reach dW
-            dqkv[rows:T].zero_()
+        # (packed layout: the rows between the last sequence and T are not the attention kernel's to write, and the weight
+        # gradient below contracts over all T rows - backward_encoder zeroes them in both dqkv buffers once per step)
         aargs = (qkv.data_ptr(), qkv.data_ptr() + 2 * H, qkv.data_ptr() + 4 * H, 3 * H, hip.ptr(mask), hip.ptr(cu),
                  hip.ptr(qoff), sv["ctx"].data_ptr(), H, dctx.data_ptr(), H, sv["lse"].data_ptr(), delta.data_ptr(),
                  dqkv.data_ptr(), dqkv.data_ptr() + 2 * H, 3 * H, dqkv.data_ptr() + 4 * H, B, NH, seq, 64,
@@ -779,7 +777,8 @@ class Engine:
                      hip.ptr(dnsp), 1.0, self.err.data_ptr(), st)
             hip.call("stonk_loss_finalize", acc[0:1].data_ptr(), cnts[0:1].data_ptr(), acc[1:2].data_ptr(),
                      cnts[1:2].data_ptr(), acc[2:4].data_ptr(), acc[4:8].data_ptr(), st)
-            out.update(loss=acc[4], masked_lm_loss=acc[5], ent_masked_lm_loss=acc[6], next_sentence_loss=acc[7])
+            out.update(loss=acc[4], masked_lm_loss=acc[5], ent_masked_lm_loss=acc[6], next_sentence_loss=acc[7],
+                       loss_terms=acc[4:8])
             save["dnsp"] = dnsp
         # F7 dense logits (what the reference always materialises: stonkgs_model.py:70-71)
         if dense_logits:
@@ -829,7 +828,9 @@ class Engine:
             h = sv[nm]
             # few output tiles (count/128 x H/128), very long contraction (the vocabulary): split-K into fp32
             dhs = self.buf("b.dhs32", (cap, H), F32)
-            dhs.zero_()
+            # (labelled rows of this head <= read rows, known to the host in the packed layout: the split-K atomics and the
+            # scatter touch no row beyond them)
+            dhs[:cap if sv["rd"] is None else min(cap, (sv["rd"]["n"] + 255) // 256 * 256)].zero_()
             # the persistent 256x256 kernel with 8 splits (<= 30 live tiles x 8 = one round of the CUs) against 128x128
             # tiles with 16: 734 us against 951 for the entity decoder (tools/bench_decoder_dgrad.py)
             # (not beside a running all-reduce - the entity decoder's bucket is in flight when the text decoder's dgrad is
@@ -920,6 +921,9 @@ class Engine:
         dy = dseq
         cu = None if plan is None else plan["cu"]
         last = cfg.num_hidden_layers - 1
+        if plan is not None and rows < T:   # what an earlier step left in the rows no sequence owns must not reach dW
+            for par in (0, 1):
+                self.buf(f"b.dqkv.{par}", (cap, 3 * H))[rows:T].zero_()
         span = self._span_begin()
         for i in reversed(range(cfg.num_hidden_layers)):
             prefix = f"bert.encoder.layer.{i}"

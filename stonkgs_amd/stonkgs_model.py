@@ -482,8 +482,8 @@ class STonKGsForPreTraining(nn.Module):
         out = self.engine.forward(t["input_ids"], t.get("attention_mask"), t.get("token_type_ids"),
                                   t["masked_lm_labels"], t["ent_masked_lm_labels"], t["next_sentence_labels"],
                                   self.training, False, True, want_hidden=False)
-        loss = out["loss"].clone()
-        self.last_loss_terms = tuple(out[k].clone() for k in _TERM_KEYS)
+        terms = out["loss_terms"].clone()          # [total, text MLM, entity MLM, NSP]: one copy out of the workspace
+        loss, self.last_loss_terms = terms[0], (terms[1], terms[2], terms[3])
         self.engine.backward(gscale, on_segment_done)
         return loss
 

@@ -960,10 +960,8 @@ class Engine:
         st = hip.stream_ptr()
         f = self.P.view
         save: dict = {}
-        # (the classification head hands out no per-position output: in training the encoder runs on the packed rows)
-        packed = need_backward and labels is not None
-        seq_out, pooled = self.encode(input_ids, attention_mask, token_type_ids, training, save,
-                                      (None, None) if packed else None)
+        # (the classification head hands out no per-position output: the encoder runs on the packed rows, training or not)
+        seq_out, pooled = self.encode(input_ids, attention_mask, token_type_ids, training, save, (None, None))
         p = cfg.hidden_dropout_prob if training else 0.0
         dropped = pooled
         if p > 0:

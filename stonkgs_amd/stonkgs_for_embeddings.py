@@ -135,7 +135,7 @@ def get_stonkgs_embeddings(preprocessed_df, pretrained_stonkgs_model_name: Optio
     rows = _rows_of(preprocessed_df, list_of_indices)
     out: List[List[float]] = []
     for ids, am, tt in _batches(rows, batch_size):
-        _, pooled = model.encode(ids, am, tt)
+        _, pooled = model.encode(ids, am, tt, pooled_only=True)
         out.extend(pooled.cpu().tolist())
     return pd.DataFrame({"embedding": out}, columns=["embedding"])
 

@@ -445,11 +445,13 @@ class STonKGsForPreTraining(nn.Module):
 
     # -------------------------------------------------------------- forward-only encoder (embedding extraction)
     @torch.no_grad()
-    def encode(self, input_ids, attention_mask=None, token_type_ids=None):
+    def encode(self, input_ids, attention_mask=None, token_type_ids=None, pooled_only: bool = False):
         """(sequence_output bf16 [B, S, H], pooler_output fp32 [B, H]) without the pre-training heads: what
         ``model(**row, return_dict=True).pooler_output`` costs in ref:stonkgs_for_embeddings.py:179 minus the two
         vocabulary-wide decoders, whose logits that caller throws away. Dropout is off (the reference's
-        ``from_pretrained`` models are in eval mode); any batch size."""
+        ``from_pretrained`` models are in eval mode); any batch size. ``pooled_only``: the caller reads the pooled vector
+        only (embedding extraction does): the encoder runs on the rows that are live keys or position 0, its last layer on
+        position 0 alone behind the QKV projection (Engine.unpad), and the first element returned is None."""
         cfg = self.config
         dev = self._device
 
@@ -465,9 +467,12 @@ class STonKGsForPreTraining(nn.Module):
         if input_ids.dim() != 2 or input_ids.shape[1] != cfg.max_position_embeddings:
             raise ValueError(f"input_ids must be [B, {cfg.max_position_embeddings}] (text half | entity half)")
         self._sync_derived()
-        seq_out, pooled = self.engine.encode(input_ids, attention_mask, token_type_ids, False, None)
+        seq_out, pooled = self.engine.encode(input_ids, attention_mask, token_type_ids, False, None,
+                                             (None, None) if pooled_only else None)
         self.engine.check_errors()
         B = input_ids.shape[0]
+        if pooled_only:
+            return None, pooled.clone()
         return seq_out.view(B, cfg.max_position_embeddings, cfg.hidden_size).clone(), pooled.clone()
 
     # -------------------------------------------------------------- fused training path (no autograd)

@@ -33,10 +33,10 @@ def test_get_stonkgs_embeddings_matches_reference_pooler_output(hip):
     assert _rel(got, gold["pooler_output"]) < 2e-2                        # vs the REFERENCE's pooler_output
     # the full forward of the pre-training model (every position a row, both decoders) gives the same vector up to the
     # rounding the packed layout moves around (the extraction runs on the live rows; its last layer on position 0 alone)
+    assert model.engine.rows_executed[5] < model.engine.rows_executed[1] // 4       # the extraction did run packed
     with torch.no_grad():
         full = model(**batch, return_dict=True).pooler_output
     assert _rel(got, full.cpu()) < 5e-3
-    assert model.engine.rows_executed[5] < model.engine.rows_executed[1] // 4       # the extraction did run packed
     # one row at a time == batched, and list_of_indices selects / orders rows
     one = get_stonkgs_embeddings(df, model=model, list_of_indices=[B - 1, 0], batch_size=1)
     torch.testing.assert_close(torch.tensor(one["embedding"].tolist()), got[[B - 1, 0]], rtol=0, atol=0)

@@ -144,6 +144,7 @@ class Engine:
         # `rocprofv3 --marker-trace --kernel-trace` timeline reads by block. Off unless STONK_ROCTX=1 (read once, here).
         self.roctx = bool(os.environ.get("STONK_ROCTX"))
         self.tn_min_k = 16384     # contraction length (rows) from which the four-wave kernel takes a weight gradient
+        self.tn_cus_small = 0     # CU share of a weight gradient of fewer than 16 256x256 tiles (0: the same as tn_cus)
         self.tn_min_tiles = 36    # 128x128 tiles of an output from which the four-wave kernel takes the gradient: 36 = the
                                   # 768 x 768 ones too (35.67 against 35.79 ms per step with 100, tools/sweep_engine_int.py)
 
@@ -250,6 +251,8 @@ class Engine:
         # ... and so does the entity decoder's 175 104 x 768 gradient (2052 unsplit tiles, device-side token count, 5.7 GB
         # operand extent - the kernel re-bases its buffer resources per K tile): 863 us against 966 alone, -0.27 ms in the step
         if tiles >= self.tn_min_tiles and K >= self.tn_min_k and M % 256 == 0 and N % 256 == 0 and not self.tn_v1:
+            if side_stream and self.tn_cus_small and tiles < 64:   # (tiles counts 128x128 ones: 64 = 16 of 256x256)
+                return -self.tn_cus_small
             return -self.tn_cus if side_stream else 0
         return max(1, min(32, 480 // tiles, K // 64))
 

@@ -144,7 +144,9 @@ class Engine:
         # `rocprofv3 --marker-trace --kernel-trace` timeline reads by block. Off unless STONK_ROCTX=1 (read once, here).
         self.roctx = bool(os.environ.get("STONK_ROCTX"))
         self.tn_min_k = 16384     # contraction length (rows) from which the four-wave kernel takes a weight gradient
-        self.tn_cus_small = 0     # CU share of a weight gradient of fewer than 16 256x256 tiles (0: the same as tn_cus)
+        # CU share of a weight gradient of fewer than 16 256x256 tiles (the 768 x 768 ones: 9 tiles; 80 CUs' worth = 8 K splits
+        # instead of 17 - half the float atomics for the same K loops: 29.81 against 29.98 ms per step; 40: 29.98 / 30.12)
+        self.tn_cus_small = 80
         self.tn_min_tiles = 36    # 128x128 tiles of an output from which the four-wave kernel takes the gradient: 36 = the
                                   # 768 x 768 ones too (35.67 against 35.79 ms per step with 100, tools/sweep_engine_int.py)
 

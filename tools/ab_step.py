@@ -21,8 +21,9 @@ attr = sys.argv[1] if len(sys.argv) > 1 else "overlap_wgrad"
 for fixed in sys.argv[2:]:   # further arguments pin switches for the whole run: engine.NAME=0/1 or args.NAME=0/1
     where, _, rest = fixed.partition(".")
     name, _, value = rest.partition("=")
-    setattr(model.engine if where == "engine" else tr.args, name, bool(int(value)))
-    print(f"pinned {where}.{name} = {bool(int(value))}", flush=True)
+    pinned = bool(int(value)) if value in ("0", "1") else int(value)   # (0 / 1: a switch; anything else: an integer attribute)
+    setattr(model.engine if where == "engine" else tr.args, name, pinned)
+    print(f"pinned {where}.{name} = {pinned}", flush=True)
 for i in range(5):
     tr.training_step(model, batches[i % 4])
 torch.cuda.synchronize()

@@ -122,8 +122,6 @@ class Engine:
         self._prefetch: Optional[dict] = None
         self._bb_stream: Optional[torch.cuda.Stream] = None
         self._pref_par = 0
-        self.prefetch_dispatched = False   # A/B switch: the prefetched backbone's GEMMs without persistent grids
-        self._dispatch_now = False
         # what ran: [rows, padded rows they stand for, encoder passes, sum over sequences of rows^2, of S^2] - bench.py prices
         # the step on the FLOPs actually executed (linear layers ~ rows, attention ~ rows^2 per sequence)
         # (sixth: rows of the last layer's feed-forward block / pooler / head; seventh: query rows x key rows of the last
@@ -296,8 +294,6 @@ class Engine:
         k = self.kernel_for.get(site)
         if k is not None:
             return k
-        if self._dispatch_now:   # (the prefetched backbone forward beside the main stream, when prefetch_dispatched is set)
-            return hip.GEMM_DISPATCHED
         return hip.GEMM_DISPATCHED if (persistent_in_backward and self.comm_overlap) else hip.GEMM_AUTO
 
     def seed(self, layer: int, site: int) -> int:
@@ -567,12 +563,10 @@ class Engine:
             # of the step that will CONSUME it (the counter advances once per encode), so a run that prefetches and one
             # that does not - or a resumed one - see the same masks
             self.seed_base += 1
-            self._dispatch_now = self.prefetch_dispatched
             try:
                 x = self.backbone_fwd(input_ids, S, B, half, training)
             finally:
                 self.seed_base -= 1
-                self._dispatch_now = False
             out.copy_(x)
             done = torch.cuda.Event()
             done.record()

@@ -57,6 +57,51 @@ __global__ __launch_bounds__(256) void small_linear_wgrad_kernel(const float* __
   }
 }
 
+// The same for M * 8 * 4 bytes of LDS or less (a batch of rows: the pooler's 64): a block owns 8 output features x 256
+// input columns, stages dpre[M][8] in LDS once and reads every x[m][k] once for the 8 features - the one-thread-per-(n, k)
+// form above re-reads dy / y per column and x per feature (83 us for the pooler's 768 x 768 from 64 rows; this one ~15).
+constexpr int WG_NT = 8;
+__global__ __launch_bounds__(256) void small_linear_wgrad_tiled_kernel(const float* __restrict__ dy,
+                                                                       const float* __restrict__ y,
+                                                                       const void* __restrict__ x, long ldx,
+                                                                       float* __restrict__ dW, float* __restrict__ db,
+                                                                       int M, int N, int K, int act) {
+  extern __shared__ __attribute__((aligned(16))) float dpre_t[];   // [M][WG_NT]
+  const bool xf32 = act & STONK_SMALL_X_F32, th = act & STONK_SMALL_TANH;
+  const int n0 = blockIdx.y * WG_NT, k = blockIdx.x * 256 + threadIdx.x;
+  for (int idx = threadIdx.x; idx < M * WG_NT; idx += 256) {
+    const int m = idx / WG_NT, n = n0 + idx % WG_NT;
+    float d = 0.f;
+    if (n < N) {
+      d = dy[(long)m * N + n];
+      if (th) {
+        const float yy = y[(long)m * N + n];
+        d *= 1.f - yy * yy;
+      }
+    }
+    dpre_t[idx] = d;
+  }
+  __syncthreads();
+  if (k < K) {
+    float acc[WG_NT];
+#pragma unroll
+    for (int j = 0; j < WG_NT; ++j) acc[j] = 0.f;
+    for (int m = 0; m < M; ++m) {
+      const float xv = load_x(x, (long)m * ldx + k, xf32);
+#pragma unroll
+      for (int j = 0; j < WG_NT; ++j) acc[j] += dpre_t[m * WG_NT + j] * xv;
+    }
+#pragma unroll
+    for (int j = 0; j < WG_NT; ++j)
+      if (n0 + j < N) dW[(long)(n0 + j) * K + k] += acc[j];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < WG_NT && n0 + threadIdx.x < N && db) {
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += dpre_t[m * WG_NT + threadIdx.x];
+    db[n0 + threadIdx.x] += s;
+  }
+}
+
 // dx[m][k] = sum_n dpre[m][n] W[n][k]; written as fp32 (dx_f32[m*K + k]) and/or ADDED into a bf16 row
 // (dx_bf16[m*ld_dxb + k] += ...: the pooler's gradient lands on position 0 of d(sequence_output)).
 // grid = (ceil(K/256), M): dpre[m][:] is staged in LDS once per block, W is read coalesced along k.
@@ -119,8 +164,12 @@ extern "C" int stonk_small_linear_bwd(const float* dy, const float* y, const voi
   if (M == 0) return STONK_OK;
   hipStream_t st = (hipStream_t)stream;
   long nk = (long)N * K;
-  hipLaunchKernelGGL(small_linear_wgrad_kernel, dim3((unsigned)((nk + 255) / 256 < 4096 ? (nk + 255) / 256 : 4096)),
-                     dim3(256), 0, st, dy, y, x, (long)ldx, dW, db, M, N, K, act);
+  if ((size_t)M * WG_NT * sizeof(float) <= 48 * 1024)
+    hipLaunchKernelGGL(small_linear_wgrad_tiled_kernel, dim3((K + 255) / 256, (N + WG_NT - 1) / WG_NT), dim3(256),
+                       (size_t)M * WG_NT * sizeof(float), st, dy, y, x, (long)ldx, dW, db, M, N, K, act);
+  else
+    hipLaunchKernelGGL(small_linear_wgrad_kernel, dim3((unsigned)((nk + 255) / 256 < 4096 ? (nk + 255) / 256 : 4096)),
+                       dim3(256), 0, st, dy, y, x, (long)ldx, dW, db, M, N, K, act);
   if (dx_f32 || dx_bf16_accum) {
     hipLaunchKernelGGL(small_linear_dgrad_kernel, dim3((K + 255) / 256, M), dim3(256), (size_t)N * sizeof(float), st, dy,
                        y, W, dx_f32, (bf16*)dx_bf16_accum, (long)ld_dxb, M, N, K, act);

@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256) void text_embed_ln_kernel(const long* __restri
 // d(position_embeddings)[s] += sum_b dx[b,s,:];  d(token_type_embeddings)[t] += sum_{(b,s): tt==t} dx[b,s,:]
 // One block per position: a thread owns 8 consecutive columns (16-byte loads) of every EG-th sequence; the row indices
 // of its sequences are fetched first and the rows then eight at a time (a thread walking the batch one dependent
-// index -> row load after the other took 155 us for 64 x 512 x 768); the EG partial sums meet in float atomics.
+// index -> row load after the other took 155 us for 64 x 512 x 768).
 constexpr int EG = 8;
 __global__ __launch_bounds__(1024) void embed_grad_kernel(const bf16* __restrict__ dx,
                                                           const long* __restrict__ token_type_ids,
@@ -665,12 +665,25 @@ __global__ __launch_bounds__(1024) void embed_grad_kernel(const bf16* __restrict
       }
     }
   }
+  // the EG partial sums of a column meet in LDS (one array, used three times); one thread per column then adds to the
+  // outputs: dpos[s] is this block's alone, the two type rows take ONE atomic per block and column (every block adding
+  // EG times into the same 2 x H addresses was 6x slower than the whole kernel)
+  __shared__ float red[EG][1024];
+  float* vals[3] = {accp, t0, t1};
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int col = 8 * c8 + j;
-    atomicAdd(dpos + (long)s * H + col, accp[j]);
-    atomicAdd(dtype + col, t0[j]);
-    if (type_rows > 1) atomicAdd(dtype + H + col, t1[j]);
+  for (int a = 0; a < 3; ++a) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[bg][8 * c8 + j] = vals[a][j];
+    __syncthreads();
+    if (a == 2 && type_rows <= 1) break;
+    for (int col = threadIdx.x; col < H; col += blockDim.x) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < EG; ++g) t += red[g][col];
+      if (a == 0) dpos[(long)s * H + col] += t;
+      else atomicAdd(dtype + (a - 1) * H + col, t);
+    }
   }
 }
 

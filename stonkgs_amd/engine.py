@@ -144,9 +144,11 @@ class Engine:
         # `rocprofv3 --marker-trace --kernel-trace` timeline reads by block. Off unless STONK_ROCTX=1 (read once, here).
         self.roctx = bool(os.environ.get("STONK_ROCTX"))
         self.tn_min_k = 16384     # contraction length (rows) from which the four-wave kernel takes a weight gradient
-        # CU share of a weight gradient of fewer than 16 256x256 tiles (the 768 x 768 ones: 9 tiles; 80 CUs' worth = 8 K splits
-        # instead of 17 - half the float atomics for the same K loops: 29.81 against 29.98 ms per step; 40: 29.98 / 30.12)
-        self.tn_cus_small = 80
+        # CU share of a weight gradient of fewer than 16 256x256 tiles (the 768 x 768 ones: 9 tiles); 0 = tn_cus. 80 CUs'
+        # worth (8 K splits instead of 17: half the float atomics for the same K loops) measured 29.81 against 29.98 ms per
+        # step - inside the box-to-box noise, and each such launch then takes longer on fewer CUs (the dominant kernel's
+        # average launch 246 -> 260 us): left at 0, kept as a switch for tools/ab_step.py
+        self.tn_cus_small = 0
         self.tn_min_tiles = 36    # 128x128 tiles of an output from which the four-wave kernel takes the gradient: 36 = the
                                   # 768 x 768 ones too (35.67 against 35.79 ms per step with 100, tools/sweep_engine_int.py)
 

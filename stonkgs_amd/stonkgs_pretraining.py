@@ -346,9 +346,11 @@ class Trainer:
                                             v.is_contiguous()))
                     else torch.as_tensor(v).to(device=dev, dtype=torch.long).contiguous()) for k, v in batch.items()}
 
-    def training_step(self, model, inputs: Dict[str, torch.Tensor], next_inputs: Optional[Dict] = None) -> torch.Tensor:
-        """`next_inputs` (optional): the batch of the NEXT call - its frozen-backbone forward is queued now, beside this
-        step's encoder forward (TrainingArguments.prefetch_backbone)."""
+    def training_step(self, model, inputs: Dict[str, torch.Tensor], num_items_in_batch=None, *,
+                      next_inputs: Optional[Dict] = None) -> torch.Tensor:
+        """hf:trainer.py training_step(model, inputs, num_items_in_batch) - the third argument is accepted and unused, as
+        the reference's loss takes no such count. `next_inputs` (keyword, optional): the batch of the NEXT call - its
+        frozen-backbone forward is queued now, beside this step's encoder forward (TrainingArguments.prefetch_backbone)."""
         model.train()
         inputs = self._on_device(inputs)
         self._next_cache = None

@@ -597,20 +597,21 @@ class Engine:
         return {102: out[0].clone(), 103: out[1].clone(), 100: out[2].clone()}
 
     # ------------------------------------------------------------------ forward
-    def _plan_rows(self, attention_mask, mlm_labels, ent_labels, B, S, half):
+    def _plan_rows(self, attention_mask, mlm_labels, ent_labels, B, S, half, keep: bool):
         """Launch the row plan of the unpadded encoder (csrc/unpad.hip) on the current stream and start the copy of the
         packed row count to the host; returns (plan dict, event). The caller queues the frozen backbone's forward - which
         does not depend on the plan - and only then waits for the event, so the GPU has work while the host learns the
-        count."""
+        count. `keep`: the plan belongs to a forward whose backward will read it (its maps live in buffers of their own,
+        which a forward-only call in between - evaluation, embedding extraction - does not touch)."""
         n = B * S
-        row_of_pos = self.buf("u.row_of_pos", (n,), I32)
-        pos_of_row = self.buf("u.pos_of_row", (n,), I32)
-        cu = self.buf("u.cu", (B + 1,), I32)
-        row_mask = self.buf("u.row_mask", (n,), torch.int64)
-        offs = self.buf("u.offsets", (2 * (B + 1),), I32)        # [sequence offsets | read-row offsets]: one copy to the host
+        u = "u" if keep else "ut"
+        row_of_pos = self.buf(f"{u}.row_of_pos", (n,), I32)
+        pos_of_row = self.buf(f"{u}.pos_of_row", (n,), I32)
+        row_mask = self.buf(f"{u}.row_mask", (n,), torch.int64)
+        offs = self.buf(f"{u}.offsets", (2 * (B + 1),), I32)     # [sequence offsets | read-row offsets]: one copy to the host
         cu, cu_rd = offs[:B + 1], offs[B + 1:]
-        read_rows = self.buf("u.read_rows", (n,), I32)
-        read_of_pos = self.buf("u.read_of_pos", (n,), I32)
+        read_rows = self.buf(f"{u}.read_rows", (n,), I32)
+        read_of_pos = self.buf(f"{u}.read_of_pos", (n,), I32)
         ws = self.buf("u.ws", (int(hip.lib().stonk_unpad_workspace_ints(B)),), I32)
         hip.call("stonk_unpad_plan", attention_mask.data_ptr(), hip.ptr(mlm_labels), hip.ptr(ent_labels), B, S, half,
                  row_of_pos.data_ptr(), pos_of_row.data_ptr(), cu.data_ptr(), row_mask.data_ptr(), read_rows.data_ptr(),
@@ -640,7 +641,7 @@ class Engine:
         p_att = cfg.attention_probs_dropout_prob if training else 0.0
         plan = ev = None
         if unpad_labels is not None and attention_mask is not None and self.unpad and B > 0:
-            plan, ev = self._plan_rows(attention_mask, unpad_labels[0], unpad_labels[1], B, S, half)
+            plan, ev = self._plan_rows(attention_mask, unpad_labels[0], unpad_labels[1], B, S, half, keep=save is not None)
         # F1 frozen backbone (no attention mask: quirk Q5; always padded - its padding positions ARE attended)
         with self.block("K1 frozen backbone fwd"):
             text_hidden = self._take_prefetched(input_ids, training)
@@ -657,7 +658,7 @@ class Engine:
         self.wait_params()   # everything above read frozen weights only; from here on the trainable ones
         T, rows, cu, mask, rd = cap, cap, None, attention_mask, None
         if plan is not None:
-            ev.synchronize()                       # (the backbone's launches are queued: the GPU is not waiting for us)
+            ev.synchronize()                       # (a backbone forward - this batch's or the next one's - is queued: the GPU has work)
             host = self._plan_host[:2 * (B + 1)].tolist()
             offs, n_read = host[:B + 1], host[2 * B + 1]
             rows = offs[B]

@@ -208,3 +208,27 @@ def test_backbone_prefetch_changes_nothing(hip):
         # the same kernels on the same data (the loss sums are float atomics: equal up to their arrival order)
         assert abs(runs[mode][0] - runs["off"][0]) < 1e-5 * abs(runs["off"][0]), mode
         assert np.allclose(runs[mode], runs["off"], rtol=0, atol=2e-3), (mode, runs[mode], runs["off"])
+
+
+def test_forward_only_call_between_forward_and_backward_leaves_the_plan_alone(hip):
+    """`encode()` (embedding extraction: forward only, scratch buffers) may run between a training forward and its
+    backward - as it could in round 2; its row plan lives in buffers of its own, so the pending backward still finds the
+    maps of ITS batch."""
+    cfg, sd, tsv_rows, _, _, _ = load_case("g2_hipsmall")
+    b0, b1 = _batches(cfg, 4)
+    grads = []
+    for interleave in (False, True):
+        m = _model(cfg, sd, tsv_rows)
+        m.train()
+        out = m(**b0)
+        if interleave:
+            m.eval()
+            _, pooled = m.encode(b1["input_ids"][:3], b1["attention_mask"][:3], b1["token_type_ids"][:3], pooled_only=True)
+            assert bool(torch.isfinite(pooled).all())
+            m.train()
+        out[0].backward()
+        m.engine.join_wgrad()
+        torch.cuda.synchronize()
+        grads.append({k: v.detach().clone() for k, v in m.named_grad_views().items()})
+    worst = max((_rel(grads[1][k], grads[0][k]), k) for k in grads[0])
+    assert worst[0] < 1e-4, worst

@@ -677,9 +677,12 @@ class Engine:
         for i, v in enumerate((T, cap, 1, sq, B * S * S, Th, sq_last)):
             self.rows_executed[i] += v
         # F2 gather + concat + embeddings LayerNorm
-        sum0 = self.buf("e.sum0", (cap, H))
-        x = self.buf("e.x0", (cap, H))
-        st0 = self.buf("e.st0", (2, cap), F32)
+        # (a forward-only call - save is None - works in scratch buffers of its own throughout: it may run between a
+        # training forward and its backward without touching what that backward reads)
+        e = "e" if save is not None else "et"
+        sum0 = self.buf(f"{e}.sum0", (cap, H))
+        x = self.buf(f"{e}.x0", (cap, H))
+        st0 = self.buf(f"{e}.st0", (2, cap), F32)
         hip.call("stonk_joint_embed_ln_fwd", input_ids.data_ptr(), hip.ptr(token_type_ids), text_hidden.data_ptr(),
                  self.kg_table.data_ptr(), f("bert.embeddings.position_embeddings.weight").data_ptr(),
                  f("bert.embeddings.token_type_embeddings.weight").data_ptr(),
@@ -700,14 +703,14 @@ class Engine:
         self._span_end("encoder_fwd", span)
         seq_out = x                                # [Th rows]: every packed row, or the read rows only
         # F4 pooler (fp32 master weights) on position 0 of every sequence
-        pooled = self.buf("h.pooled", (B, H), F32)
+        pooled = self.buf(f"{e}.pooled", (B, H), F32)
         first_rows = None if plan is None else (cu if rd is None else plan["cu_rd"])
         if plan is None:
             first, ld_first = seq_out, S * H
         else:   # packed: position 0 of sequence b is row cu[b] (among the read rows: read_offsets[b])
-            nb = self.buf("u.nb", (1,), I32)
+            nb = self.buf(f"{e}.nb", (1,), I32)
             nb.fill_(B)
-            first, ld_first = self.buf("h.first", ((B + 127) // 128 * 128, H)), H
+            first, ld_first = self.buf(f"{e}.first", ((B + 127) // 128 * 128, H)), H
             hip.call("stonk_gather_rows_bf16", seq_out.data_ptr(), H, first_rows.data_ptr(), nb.data_ptr(), first.data_ptr(),
                      H, H, first.shape[0], st)
         hip.call("stonk_small_linear_fwd", first.data_ptr(), ld_first, f("bert.pooler.dense.weight").data_ptr(),
@@ -913,7 +916,7 @@ class Engine:
         if plan is None:
             acc, ld_acc = dseq, S * H
         else:   # packed: position 0 of sequence b is row first_rows[b] - its gradient rows are gathered, added to, scattered back
-            nb = self.buf("u.nb", (1,), I32)
+            nb = self.buf("e.nb", (1,), I32)
             nb.fill_(B)
             acc, ld_acc = self.buf("b.dfirst", ((B + 127) // 128 * 128, H)), H
             hip.call("stonk_gather_rows_bf16", dseq.data_ptr(), H, first_rows.data_ptr(), nb.data_ptr(), acc.data_ptr(), H,

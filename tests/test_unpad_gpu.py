@@ -211,9 +211,9 @@ def test_backbone_prefetch_changes_nothing(hip):
 
 
 def test_forward_only_call_between_forward_and_backward_leaves_the_plan_alone(hip):
-    """`encode()` (embedding extraction: forward only, scratch buffers) may run between a training forward and its
-    backward - as it could in round 2; its row plan lives in buffers of its own, so the pending backward still finds the
-    maps of ITS batch."""
+    """`encode()` (embedding extraction: forward only) may run between a training forward and its backward: it works in
+    scratch buffers of its own throughout - embeddings, layers, pooler, row plan - so the pending backward still finds the
+    activations and the maps of ITS batch."""
     cfg, sd, tsv_rows, _, _, _ = load_case("g2_hipsmall")
     b0, b1 = _batches(cfg, 4)
     grads = []

@@ -31,6 +31,27 @@ constexpr float LN2 = 0.6931471805599453f;
 constexpr float NEG_MASK = -0x1p100f;
 constexpr float NEG_INIT = -0x1p120f;
 
+// The block multipliers of one row (four consecutive entries of STONK_C2_BLK) or of one column (every fourth), selected
+// per lane at kernel entry from literals (three compares and twelve selects, no memory access).
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+__device__ __forceinline__ uint32_t pick4(int i, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d));
+}
+__device__ __forceinline__ u32x4 c2_of_row(int row) {
+  const int i = row & 3;
+  u32x4 o;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) o[u] = pick4(i, STONK_C2_BLK[u], STONK_C2_BLK[4 + u], STONK_C2_BLK[8 + u], STONK_C2_BLK[12 + u]);
+  return o;
+}
+__device__ __forceinline__ u32x4 c2_of_col(int col) {
+  const int i = col & 3;
+  u32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = pick4(i, STONK_C2_BLK[4 * j], STONK_C2_BLK[4 * j + 1], STONK_C2_BLK[4 * j + 2], STONK_C2_BLK[4 * j + 3]);
+  return o;
+}
+
 struct AttnArgs {
   const bf16* q;
   const bf16* k;
@@ -182,10 +203,11 @@ __device__ __forceinline__ void stage_store(const Stage2& s, char* tile, int tid
 // Every kernel below runs the same pipeline: tile t+1 is fetched into registers while tile t is computed from LDS
 // stage t&1, written to the other stage when the compute is done, ONE barrier per tile.
 //
-// Dropout: element (query row, key) is kept iff stonk_quad_keep(stonk_quad_round1(rowkey(flat (b,h,q)), colkey(key >> 2)),
-// C2_QUAD[key & 3]) - one first hash round per QUAD of keys (common.h). Both keys are linear, so the kernels with the query
-// on the lane add a compile-time constant to the tile's quad key per four elements and the kernel with the key on the lane
-// does the same with the row key per element. The 1/(1-p) factor never touches an
+// Dropout: element (query row, key), row = the flat (b,h,q) index, is kept iff
+// stonk_blk_keep(stonk_blk_round1(rowkey(row >> 2), colkey(key >> 2)), C2_BLK[4 (row & 3) + (key & 3)]) - one first hash
+// round per 4 x 4 BLOCK of scores (common.h). Both keys are linear, so the kernels with the query on the lane add a
+// compile-time constant to the tile's key-quad key per four elements and the kernel with the key on the lane does the same
+// with the row-quad key; either keeps its four multipliers in registers. The 1/(1-p) factor never touches an
 // element: it is folded into the output normalisation (forward, dV) or into delta and the final scale (dQ, dK).
 
 // Workgroup -> (128-row block, head, sequence). Workgroups are dispatched round-robin over the 8 XCDs in linear order, so
@@ -307,8 +329,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
   const bf16* kbase = p.k + tok0 * p.ld + h * HD;
   const bf16* vbase = p.v + tok0 * p.ld + h * HD;
   const int ntiles = (n + TK - 1) / TK;
-  const uint32_t rk = stonk_rowkey((uint32_t)((b * p.NH + h) * S + q0 + r), p.seed);
+  const uint32_t rk = stonk_rowkey((uint32_t)((b * p.NH + h) * S + q0 + r) >> 2, p.seed);   // row QUAD of this lane's query
   const uint32_t ck_lane = stonk_colkey((uint32_t)hh);   // key QUADS: this lane's keys start at 4 hh = quad hh
+  u32x4 c2u = {0u, 0u, 0u, 0u};   // the block multipliers of this lane's row (q0 and the flat (b,h) offset are multiples of 4)
+  if (DROPOUT) c2u = c2_of_row(r);
 
   Stage2 sk, sv;
   long mreg = 1;
@@ -392,12 +416,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
           uint32_t y8 = 0;
           if (DROPOUT) {
             const uint32_t cj = (uint32_t)((sub * 32 + 16 * ks + 8 * (j >> 2)) >> 2) * STONK_G_COL;
-            y8 = stonk_quad_round1(rk, ckt + cj);
+            y8 = stonk_blk_round1(rk, ckt + cj);
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             e[j + u] = s[sub][8 * ks + j + u];
-            if (DROPOUT) e[j + u] = stonk_quad_keep(y8, STONK_C2_QUAD[u], p.drop_thr32) ? e[j + u] : 0.f;
+            if (DROPOUT) e[j + u] = stonk_blk_keep(y8, c2u[u], p.drop_thr32) ? e[j + u] : 0.f;
           }
         }
         const bf16x8 pf = pack8(e);
@@ -492,8 +516,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   const bf16* kbase = p.k + tok0 * p.ld + h * HD;
   const bf16* vbase = p.v + tok0 * p.ld + h * HD;
   const int ntiles = (n + TK - 1) / TK;
-  const uint32_t rk = stonk_rowkey((uint32_t)stat, p.seed);
-  const uint32_t ck_lane = stonk_colkey((uint32_t)hh);   // key quads, as in the forward
+  const uint32_t rk = stonk_rowkey((uint32_t)stat >> 2, p.seed);   // row quad, key quads and multipliers as in the forward
+  const uint32_t ck_lane = stonk_colkey((uint32_t)hh);
+  u32x4 c2u = {0u, 0u, 0u, 0u};
+  if (DROPOUT) c2u = c2_of_row(r);
 
   Stage2 sk, sv;
   long mreg = 1;
@@ -556,9 +582,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
         const f32x2 pr = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
         f32x2 dpv = {dp[i], dp[i + 1]};
         if (DROPOUT) {
-          if ((i & 2) == 0) y8q = stonk_quad_round1(rk, ckt + (uint32_t)((sub * 32 + 8 * (i >> 2)) >> 2) * STONK_G_COL);
-          dpv[0] = stonk_quad_keep(y8q, STONK_C2_QUAD[i & 2], p.drop_thr32) ? dpv[0] : 0.f;
-          dpv[1] = stonk_quad_keep(y8q, STONK_C2_QUAD[(i & 2) + 1], p.drop_thr32) ? dpv[1] : 0.f;
+          if ((i & 2) == 0) y8q = stonk_blk_round1(rk, ckt + (uint32_t)((sub * 32 + 8 * (i >> 2)) >> 2) * STONK_G_COL);
+          dpv[0] = stonk_blk_keep(y8q, c2u[i & 2], p.drop_thr32) ? dpv[0] : 0.f;
+          dpv[1] = stonk_blk_keep(y8q, c2u[(i & 2) + 1], p.drop_thr32) ? dpv[1] : 0.f;
         }
         const f32x2 ds = pr * (dpv - (f32x2){dlt_s, dlt_s});  // dS^T (up to the folded 1/(1-p))
         s[i] = ds[0];
@@ -633,9 +659,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   const bf16* dbase = p.dout + tok0 * p.lddo + h * HD;
   const long statbase = (long)(b * p.NH + h) * S;
   const int ntiles = (nq + TK - 1) / TK;   // QUERY tiles
-  const uint32_t rk_lane = stonk_rowkey((uint32_t)(statbase + 4 * hh), p.seed);
+  // row QUADS: an accumulator group g of this lane holds the query rows 8 g + 4 hh .. + 3 of a 32-row block = one quad
+  const uint32_t rk_lane = stonk_rowkey((uint32_t)(statbase >> 2) + (uint32_t)hh, p.seed);
   const uint32_t ck = stonk_colkey((uint32_t)((k0 + r) >> 2));   // this lane's key: its quad ...
-  const uint32_t c2 = stonk_quad_c2((uint32_t)(k0 + r));         // ... and its place in it
+  u32x4 c2j = {0u, 0u, 0u, 0u};                                  // ... and the block multipliers of its column
+  if (DROPOUT) c2j = c2_of_col(r);
   const float inv_ds = DROPOUT ? 1.f / p.drop_scale : 1.f;
 
   Stage2 sq, sd;
@@ -682,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
     const float* Ls = (const float*)(Qs + 2 * TILEB);
     const float* Dl = Ls + TK;
     if (qt + 1 < ntiles) load_tile(qt + 1);
-    const uint32_t rkt = rk_lane + (uint32_t)(qt * TK) * STONK_G_ROW;
+    const uint32_t rkt = rk_lane + (uint32_t)(qt * TK / 4) * STONK_G_ROW;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       if (!wave_live) break;
@@ -701,6 +729,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
       for (int g = 0; g < 4; ++g) {
         const f32x4 nls = *(const f32x4*)(Ls + sub * 32 + 8 * g + 4 * hh);
         const f32x4 dl = *(const f32x4*)(Dl + sub * 32 + 8 * g + 4 * hh);   // -(1-p) * delta
+        uint32_t y8 = 0;
+        if (DROPOUT) y8 = stonk_blk_round1(rkt + (uint32_t)(sub * 8 + 2 * g) * STONK_G_ROW, ck);
 #pragma unroll
         for (int j = 0; j < 4; j += 2) {
           const int i = 4 * g + j;
@@ -709,10 +739,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
           f32x2 pd = pr;
           if (DROPOUT) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const uint32_t rj = (uint32_t)(sub * 32 + 8 * g + j + u) * STONK_G_ROW;
-              pd[u] = stonk_quad_keep(stonk_quad_round1(rkt + rj, ck), c2, p.drop_thr32) ? pr[u] : 0.f;
-            }
+            for (int u = 0; u < 2; ++u) pd[u] = stonk_blk_keep(y8, c2j[j + u], p.drop_thr32) ? pr[u] : 0.f;
           }
           // dS = P (drop(dP) - delta) = dropped P . dP + P . (-delta): one select per score instead of two
           const f32x2 ds = pk_fma(pd, (f32x2){dp[i], dp[i + 1]}, pr * (f32x2){dl[j], dl[j + 1]});

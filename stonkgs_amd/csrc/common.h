@@ -100,22 +100,24 @@ __device__ __forceinline__ bool stonk_keep_key(uint32_t rowkey, uint32_t colkey,
   const uint32_t y = __umul24(x, 0xB5297Bu) + x;
   return __umul24(y >> 8, 0x68E31Du) >= thr32;
 }
-// The same generator for a QUAD of neighbouring columns (4j .. 4j+3) - the attention probabilities' dropout: the first
-// round is computed once per quad from the quad's key (colkey(j)), the last round four times with different multipliers;
-// column 4j's decision is stonk_keep_key(rowkey, colkey(j)). A lane that walks the keys of one query (forward, dQ: four
-// consecutive keys per accumulator group) pays 4 VALU operations per score instead of 7; a lane that owns one key (dK/dV)
-// keeps its multiplier in a register and pays what it paid. Keep rate, row / column sums and the joint drop rates inside
-// a quad (pairs and triples), across quads, along rows, columns and 2x2 minors are those of independent draws (checked
-// offline as above, twelve seed / row-range combinations).
-constexpr uint32_t STONK_C2_QUAD[4] = {0x68E31Du, 0x9E3779u, 0xC2B2AFu, 0x27D4EBu};
-__device__ __forceinline__ uint32_t stonk_quad_c2(uint32_t col) {
-  return (col & 2) ? ((col & 1) ? 0x27D4EBu : 0xC2B2AFu) : ((col & 1) ? 0x9E3779u : 0x68E31Du);
-}
-__device__ __forceinline__ uint32_t stonk_quad_round1(uint32_t rowkey, uint32_t pairkey) {
-  const uint32_t x = rowkey ^ pairkey;
+// The same generator for a 4 x 4 BLOCK of (row, column) neighbours (rows 4i .. 4i+3, columns 4j .. 4j+3) - the attention
+// probabilities' dropout: the first round is computed once per block from the block's keys (rowkey(i), colkey(j)), the
+// last round once per element with one of sixteen multipliers, STONK_C2_BLK[4 (row & 3) + (column & 3)]. Whichever way a
+// lane walks the scores, four of its consecutive elements share a first round: a lane that walks the keys of one query
+// (forward, dQ: four consecutive keys per accumulator group) keeps the four multipliers of its row in registers, a lane
+// that owns one key and walks the queries (dK/dV: four consecutive query rows per accumulator group) the four of its
+// column - 4 VALU operations per score in all three kernels (the dK/dV kernel paid 7 while only the columns were grouped).
+// The multipliers were chosen by exhaustive enumeration of the 2^24 first-round values (tools/dropout_multipliers.py):
+// every pairwise joint drop rate of two block members is within 0.3 % of p^2 and every triple within 1.3 % of p^3 at
+// p = 0.1 and 0.25, and the number of drops in a block follows the binomial to 0.1 % up to 5 of 16.
+constexpr uint32_t STONK_C2_BLK[16] = {0x45821Fu, 0xFAC0C5u, 0xD90A1Bu, 0xE6B85Bu, 0xE11EE7u, 0x6E41B9u, 0xB8115Du, 0xB1494Bu,
+                                       0xBF440Fu, 0xA96C25u, 0x7B570Fu, 0xA2609Du, 0x98207Du, 0xB5677Du, 0x82C471u, 0xAC3C19u};
+// first round of a block: rowkey = stonk_rowkey(row >> 2, seed), colkey = stonk_colkey(column >> 2)
+__device__ __forceinline__ uint32_t stonk_blk_round1(uint32_t rowkey, uint32_t colkey) {
+  const uint32_t x = rowkey ^ colkey;
   return (__umul24(x, 0xB5297Bu) + x) >> 8;
 }
-__device__ __forceinline__ bool stonk_quad_keep(uint32_t y8, uint32_t c2, uint32_t thr32) { return __umul24(y8, c2) >= thr32; }
+__device__ __forceinline__ bool stonk_blk_keep(uint32_t y8, uint32_t c2, uint32_t thr32) { return __umul24(y8, c2) >= thr32; }
 __device__ __forceinline__ bool stonk_keep(uint32_t row, uint32_t col, uint32_t seedmix, uint32_t thr32) {
   return stonk_keep_key(stonk_rowkey(row, seedmix), stonk_colkey(col), thr32);
 }

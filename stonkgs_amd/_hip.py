@@ -25,7 +25,7 @@ EPI_SAVE_PREACT = 1 << 5
 EPI_GELU_BWD = 1 << 6
 EPI_DROPOUT = 1 << 7
 EPI_AUX_GRAD = 1 << 8   # aux = gelu'(pre-activation): stored by SAVE_PREACT (with GELU), multiplied in by GELU_BWD
-GEMM_AUTO, GEMM_TILE128, GEMM_WAVE8, GEMM_WAVE4, GEMM_WAVE4_192, GEMM_DISPATCHED = 0, 1, 2, 3, 4, 5   # stonk_gemm_nt_bf16 `kernel`
+GEMM_AUTO, GEMM_TILE128, GEMM_WAVE8, GEMM_WAVE4, GEMM_WAVE4_192, GEMM_DISPATCHED, GEMM_DISPATCHED2 = 0, 1, 2, 3, 4, 5, 6   # stonk_gemm_nt_bf16 `kernel`
 LN_DROPOUT = 1 << 0
 SMALL_TANH = 1
 SMALL_X_F32 = 16

@@ -21,7 +21,7 @@ using namespace stonk_gemm;
 
 // defined in gemm256.hip
 int stonk_gemm256_launch(const GemmArgs& a, int out_mode, hipStream_t st);
-int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, int tile_n, bool one_item, hipStream_t st);
+int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, int tile_n, int items_per_wg, hipStream_t st);
 
 namespace {
 
@@ -302,7 +302,7 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
                                   const int* m_dev, const int* k_dev, float drop_p, uint32_t seed, int kernel,
                                   void* stream) {
   STONK_CHECK_ARG(A && B && C, STONK_EINVAL);
-  STONK_CHECK_ARG(kernel >= STONK_GEMM_AUTO && kernel <= STONK_GEMM_DISPATCHED, STONK_EINVAL);
+  STONK_CHECK_ARG(kernel >= STONK_GEMM_AUTO && kernel <= STONK_GEMM_DISPATCHED2, STONK_EINVAL);
   STONK_CHECK_ARG(M >= 0 && N > 0 && K > 0, STONK_ESHAPE);
   STONK_CHECK_ARG(N % BN == 0 && K % BK == 0, STONK_ESHAPE);
   STONK_CHECK_ARG(split_k >= 1 && split_k <= K / BK, STONK_ESHAPE);
@@ -360,7 +360,7 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   //  * the label-sparse decoders (fp16 / fp32 output) and wide launches that tile evenly by 256 stay on the eight-wave kernel;
   //  * everything else (N = 768 without a side operand, split-K atomics, small M) keeps the 128x128 tiles.
   const bool w4_side = (flags & (STONK_EPI_RESID | STONK_EPI_GELU_BWD)) != 0;
-  const bool dispatched = kernel == STONK_GEMM_DISPATCHED;
+  const bool dispatched = kernel == STONK_GEMM_DISPATCHED || kernel == STONK_GEMM_DISPATCHED2;
   int k = dispatched ? STONK_GEMM_AUTO : kernel;
   if (k == STONK_GEMM_AUTO)
     k = (w4_ok && w4_side && M >= 1024 && out_mode == STONK_EPI_OUT_BF16) ? STONK_GEMM_WAVE4
@@ -380,7 +380,8 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
     STONK_CHECK_ARG(w4_ok, STONK_ESHAPE);
     // chosen by AUTO: the launcher also picks the tile width (256x192 where N = 768 / 2304 quantise better on 256 CUs)
     const bool chosen = kernel == STONK_GEMM_AUTO || dispatched;
-    return stonk_gemm_w4_launch(a, out_mode, chosen ? 0 : (k == STONK_GEMM_WAVE4 ? 256 : 192), dispatched, st);
+    return stonk_gemm_w4_launch(a, out_mode, chosen ? 0 : (k == STONK_GEMM_WAVE4 ? 256 : 192),
+                                !dispatched ? 0 : (kernel == STONK_GEMM_DISPATCHED2 ? 2 : 1), st);
   }
   if (k == STONK_GEMM_WAVE8 && dispatched) k = STONK_GEMM_TILE128;
   if (k == STONK_GEMM_WAVE8) {

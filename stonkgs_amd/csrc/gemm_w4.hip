@@ -532,10 +532,11 @@ int launch_w4(const GemmArgs& a, int grid, hipStream_t st) {
 
 // Launcher used by stonk_gemm_nt_bf16 (gemm_bf16.hip). Requires K % 64 == 0 and an EVEN number of K tiles per work item
 // (the K loop is unrolled by two; every GEMM of the STonKGs step has K = 768, 2304 or 3072). tile_n: 0 = choose, 256, 192.
-// one_item: grid = work items instead of one persistent workgroup per CU (STONK_GEMM_DISPATCHED) - the hardware dispatcher
-// is then the work queue and a workgroup that gets its CU late delays nobody else; the workgroups still take their items
-// in XCD-contiguous runs.
-int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, int tile_n, bool one_item, hipStream_t st) {
+// items_per_wg > 0: grid = work items / items_per_wg instead of one persistent workgroup per CU (STONK_GEMM_DISPATCHED: 1,
+// _DISPATCHED2: 2) - the hardware dispatcher is then the work queue and a workgroup that gets its CU late delays nobody
+// else; the workgroups still take their items in XCD-contiguous runs, and with two items the second one's operands are
+// prefetched across the tile boundary as in the persistent form.
+int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, int tile_n, int items_per_wg, hipStream_t st) {
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -558,7 +559,7 @@ int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, int tile_n, bool one_i
   }
   if (tile_n == 192) {
     const long tiles = ntm * (a.N / 192) * a.split_k;
-    const int grid = (int)((tiles < n_cu || one_item) ? tiles : n_cu);
+    const int grid = (int)(items_per_wg > 0 ? (tiles + items_per_wg - 1) / items_per_wg : (tiles < n_cu ? tiles : n_cu));
     switch (epi) {
       case 0: return launch_w4<0, 0, 192>(a, grid, st);
       case B: return launch_w4<0, B, 192>(a, grid, st);
@@ -568,7 +569,7 @@ int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, int tile_n, bool one_i
     }
   }
   const long tiles = ntm * ((a.N + 255) / 256) * a.split_k;
-  const int grid = (int)((tiles < n_cu || one_item) ? tiles : n_cu);
+  const int grid = (int)(items_per_wg > 0 ? (tiles + items_per_wg - 1) / items_per_wg : (tiles < n_cu ? tiles : n_cu));
   if (out_mode == 1) return epi == 0 ? launch_w4<1, 0>(a, grid, st) : launch_w4<1, -1>(a, grid, st);
   if (out_mode == 2) return launch_w4<2, 0>(a, grid, st);
   switch (epi) {   // the combinations the STonKGs step uses are compiled with constant flags

@@ -30,6 +30,7 @@
                                  prefetch across tile boundaries), 128x128 tiles where AUTO would take the eight-wave kernel. For a \
                                  launch beside which another stream (a collective) holds CUs: a persistent grid with a static tile \
                                  split waits for its last workgroup to get a CU */
+#define STONK_GEMM_DISPATCHED2 6 /* the same with TWO work items per workgroup (grid = tiles / 2): every second tile boundary                                  keeps its prefetch, the dispatcher still hands out the work in pieces far smaller than a                                  CU's share; where DISPATCHED runs 128x128 tiles this is DISPATCHED */
 // --- stonk_layernorm_* `flags` ---
 #define STONK_LN_DROPOUT (1 << 0)
 // --- stonk_small_linear_* `act` ---

@@ -14,6 +14,7 @@ import contextlib
 
 import math
 import os
+import time
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -88,6 +89,9 @@ class Engine:
         # same four-wave kernel with one work item per workgroup, so the hardware dispatcher hands out the tiles (one GPU,
         # nothing beside it: +0.9 ms per step against the persistent grids; the 128x128 kernel used here before: +1.7 ms).
         self.comm_overlap = False
+        # ... with TWO work items per workgroup (STONK_GEMM_DISPATCHED2, round 3): every second tile boundary keeps its
+        # prefetch; measured on one GPU with nothing beside it (tools/ab_step.py dispatched_pairs engine.comm_overlap=1)
+        self.dispatched_pairs = True
         self.decoder_dgrad_256 = True
         # Which of the library's three NT kernels runs a launch is the LIBRARY's choice (STONK_GEMM_AUTO: from shape and
         # epilogue, stonk_gemm_nt_bf16) - except where the engine knows what the library cannot: that an all-reduce is
@@ -134,6 +138,9 @@ class Engine:
         # stream after the last parameter write - called before the first trainable weight is read and by every accessor.
         self._opt_stream: Optional[torch.cuda.Stream] = None
         self._params_ready: Optional[torch.cuda.Event] = None
+        # tools/step_marks.py: a list to collect (name, host time, event on the current stream, was the optimizer's
+        # "parameters final" event already complete) at a few points of the step; None (default) = nothing is recorded
+        self.marks: Optional[list] = None
         self._wgrad_done: Dict[int, torch.cuda.Event] = {}   # layer parity -> side-stream event after its last wgrad
         self._wt_desc = None   # (device table, entries, tiles) of the batched W^T refresh
         # development switches, read ONCE here: the 128x128 weight-gradient kernel everywhere / the CU share of the
@@ -190,6 +197,14 @@ class Engine:
             yield
         finally:
             torch.cuda.nvtx.range_pop()
+
+    def mark(self, name: str) -> None:
+        if self.marks is None:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        pr = self._params_ready
+        self.marks.append((name, time.perf_counter(), ev, None if pr is None else pr.query()))
 
     def wait_params(self) -> None:
         """Order the current stream after the last optimizer step, if it ran on the optimizer stream (no host
@@ -296,7 +311,9 @@ class Engine:
         k = self.kernel_for.get(site)
         if k is not None:
             return k
-        return hip.GEMM_DISPATCHED if (persistent_in_backward and self.comm_overlap) else hip.GEMM_AUTO
+        if persistent_in_backward and self.comm_overlap:
+            return hip.GEMM_DISPATCHED2 if self.dispatched_pairs else hip.GEMM_DISPATCHED
+        return hip.GEMM_AUTO
 
     def seed(self, layer: int, site: int) -> int:
         return (self.seed_base * 0x9E3779B1 + layer * 64 + site) & 0xFFFFFFFF
@@ -658,7 +675,9 @@ class Engine:
         self.wait_params()   # everything above read frozen weights only; from here on the trainable ones
         T, rows, cu, mask, rd = cap, cap, None, attention_mask, None
         if plan is not None:
+            self.mark("plan_wait")
             ev.synchronize()                       # (a backbone forward - this batch's or the next one's - is queued: the GPU has work)
+            self.mark("plan_known")
             host = self._plan_host[:2 * (B + 1)].tolist()
             offs, n_read = host[:B + 1], host[2 * B + 1]
             rows = offs[B]
@@ -694,6 +713,7 @@ class Engine:
         if hint is not None:   # (after an inline backbone forward: behind the kernel above, the last reader of its scratch)
             self.prefetch_backbone(hint, training)
         # F3 encoder
+        self.mark("encoder_fwd_begin")
         span = self._span_begin()
         last = cfg.num_hidden_layers - 1
         for i in range(cfg.num_hidden_layers):
@@ -957,6 +977,7 @@ class Engine:
                  g_("bert.embeddings.token_type_embeddings.weight").data_ptr(), B, S, H, cfg.type_vocab_size,
                  0 if plan is None else plan["row_of_pos"].data_ptr(), st)
         notify("bert.embeddings")
+        self.mark("backward_end")
         self.join_wgrad()
 
     # ------------------------------------------------------------------ sequence classification head (config 5)

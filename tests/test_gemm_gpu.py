@@ -201,7 +201,7 @@ def test_gemm_device_row_count_and_dropout(hip):
 
 
 @pytest.mark.parametrize("M,N,K,fl", [(4096, 768, 768, 0), (2048, 768, 3072, "resid"), (2048, 3072, 768, "gelu_bwd"), (1024, 2304, 768, "bias"),
-                                      (1024, 1536, 768, 0), (300, 768, 768, 0)])
+                                      (1024, 1536, 768, 0), (300, 768, 768, 0), (1280, 768, 768, 0)])
 def test_gemm_dispatched_is_auto_without_a_persistent_grid(hip, M, N, K, fl):
     """STONK_GEMM_DISPATCHED: the launcher's own choice, one work item per workgroup (the form for launches beside a
     collective). Same kernel, same tiles, same arithmetic: bit-identical to AUTO - also where AUTO takes the eight-wave
@@ -216,11 +216,12 @@ def test_gemm_dispatched_is_auto_without_a_persistent_grid(hip, M, N, K, fl):
     elif fl == "bias":
         flags, kw = hip.EPI_BIAS, {"bias": torch.randn(N, device="cuda")}
     auto = _gemm(hip, A, B, flags=flags, kernel=hip.GEMM_AUTO, **kw)
-    disp = _gemm(hip, A, B, flags=flags, kernel=hip.GEMM_DISPATCHED, **kw)
-    if N == 1536:
-        torch.testing.assert_close(disp.float(), auto.float(), rtol=2e-2, atol=2e-2)
-    else:
-        assert torch.equal(auto, disp)
+    for kernel in (hip.GEMM_DISPATCHED, hip.GEMM_DISPATCHED2):   # (one / two work items per workgroup; odd tile counts included)
+        disp = _gemm(hip, A, B, flags=flags, kernel=kernel, **kw)
+        if N == 1536:
+            torch.testing.assert_close(disp.float(), auto.float(), rtol=2e-2, atol=2e-2)
+        else:
+            assert torch.equal(auto, disp)
 
 
 def test_gemm_bad_arguments(hip):

@@ -63,6 +63,9 @@ for name, fn in (("weight gradient, four-wave 256x256, all CUs", lambda: wgrad(0
                  ("weight gradient, four-wave 256x256, 160 CUs", lambda: wgrad(-160)),
                  ("weight gradient, 128x128 split 12", lambda: wgrad(12)),
                  ("NT 32768x3072x768, persistent 256x256", lambda: nt(hip.GEMM_WAVE8)),
+                 ("NT 32768x3072x768, four-wave persistent", lambda: nt(hip.GEMM_WAVE4)),
+                 ("NT 32768x3072x768, four-wave DISPATCHED (one item per workgroup)", lambda: nt(hip.GEMM_DISPATCHED)),
+                 ("NT 32768x3072x768, four-wave DISPATCHED2 (two items per workgroup)", lambda: nt(hip.GEMM_DISPATCHED2)),
                  ("NT 32768x3072x768, 128x128", lambda: nt(hip.GEMM_TILE128))):
     for _ in range(2):
         fn()

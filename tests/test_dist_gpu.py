@@ -74,14 +74,16 @@ def test_rccl_path_executes_in_a_one_rank_group(hip):
         assert tr2.sync.shard and tr2.optimizer.spans == [(lo, hi) for lo, hi in tr2.sync.buckets]
     finally:
         dist.destroy_process_group()
-    assert l1 == pytest.approx(l0, rel=1e-5)
+    # (the second step's loss sits behind one Adam step of lr 1e-3 on gradients whose fp32 atomics reorder from run to run:
+    # two plain runs differ by 1-2e-5 of it; a wrong bucket moves it by percents)
+    assert l1 == pytest.approx(l0, rel=5e-5)
     # fp32 atomics reorder addends from run to run, and Adam turns last-bit differences of near-zero gradients into +-lr
     # steps: compare the two-step displacement of the parameters, and bound the largest difference by two lr-sized steps
     d = (p1 - p0).abs()
     moved1, moved0 = p1 - init, p0 - init
     cos = torch.nn.functional.cosine_similarity(moved1.flatten(), moved0.flatten(), dim=0).item()
     assert float(d.max()) <= 2.1e-3 and cos > 0.999, (float(d.max()), cos)
-    assert l2 == pytest.approx(l0, rel=1e-5)
+    assert l2 == pytest.approx(l0, rel=5e-5)
     cos2 = torch.nn.functional.cosine_similarity((p2 - init).flatten(), moved0.flatten(), dim=0).item()
     assert float((p2 - p0).abs().max()) <= 2.1e-3 and cos2 > 0.999, (float((p2 - p0).abs().max()), cos2)
 

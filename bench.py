@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 # gemm_tn_w4_kernel (12L/768, average of its 47 launches per step on the unpadded rows): 239.8 MB fetched (FETCH_SIZE
 # doubled, the gfx950 correction of MI355X_MICROARCH.md) + 58.4 MB of float atomics written (profiles/r03_pmc_traffic.csv;
 # algorithmic: 193.5 MB; round 2, 50 launches on padded rows: 283.9 + 57.2)
-TRAFFIC_BYTES = {("150k", "tn_w4"): 298.2e6}
+TRAFFIC_BYTES = {("150k", "tn_w4"): 301.3e6}
 KERNEL_NOTES = {
     "tn_w4": "gemm_tn_w4_kernel (weight + bias gradients: bf16 MFMA 32x32x16, 256x256 tiles over 64-token steps, four waves, "
              "transposed LDS reads, split-K fp32 atomics)",

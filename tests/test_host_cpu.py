@@ -105,6 +105,21 @@ def test_library_exports_every_declared_symbol():
     assert _hip.lib().stonk_layernorm_bwd_workspace_floats(0, 768) == 0
 
 
+def test_ctypes_constants_mirror_the_flag_header():
+    """stonkgs_amd/_hip.py repeats the values of csrc/stonk_flags.h (what include/stonk_hip.h hands a C caller): every
+    `#define STONK_<NAME> <value>` that has a Python twin must agree with it, and the kernel selectors must all have one."""
+    text = open(os.path.join(ROOT, "stonkgs_amd", "csrc", "stonk_flags.h")).read()
+    defs = {}
+    for name, value in re.findall(r"^#define STONK_(\w+) +(\(1 << \d+\)|\d+)", text, flags=re.M):
+        defs[name] = eval(value)
+    assert len(defs) > 20
+    twins = {n: getattr(_hip, n) for n in defs if hasattr(_hip, n)}
+    assert twins and all(twins[n] == defs[n] for n in twins), {n: (twins[n], defs[n]) for n in twins if twins[n] != defs[n]}
+    for n in defs:
+        if n.startswith("GEMM_"):
+            assert n in twins, n
+
+
 def test_bad_arguments_are_rejected_without_touching_the_gpu():
     lib = _hip.lib()
     assert lib.stonk_gemm_nt_bf16(0, 0, 0, 0, 0, 0, 1, 128, 64, 0, 0, 0, 0, 0, 0, 1.0, 1, 0, 0, 0.0, 0, 0, 0) == -1

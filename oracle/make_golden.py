@@ -10,7 +10,8 @@ Nothing here runs on the GPU box; the fixtures it writes are data only (ints / f
 
     python oracle/make_golden.py          # rewrites tests/golden/*.npz, *.json
     python oracle/make_golden.py shape    # only g3_shapetrue; `f3` = only the TSV / checkpoint cases; `splits` = only g7;
-                                          # `curve` / `curve_small` = only the loss-curve cases g11 / g12
+                                          # `curve` / `curve_small` = only the loss-curve cases g11 / g12;
+                                          # `bf16_grads` = only g16 / g17 (reference gradients under bf16 autocast); `cls` = only g6
 """
 from __future__ import annotations
 
@@ -396,6 +397,154 @@ def shape_true_case(name, sm, pre, cfg: orc.OracleConfig, B, seed):
     print(name, "loss", float(out.loss), "grad_norm", float(total_norm))
 
 
+def _grad_envelope(params_fp32, params_bf16):
+    """Per-tensor deviation of one backward pass from another: relative L2 error, cosine, norm ratio."""
+    names, rel, cos, ratio = [], [], [], []
+    for k, g in params_fp32.items():
+        a, b = params_bf16[k].double().flatten(), g.double().flatten()
+        nb = float(b.norm())
+        names.append(k)
+        rel.append(float((a - b).norm()) / (nb if nb >= 1e-5 else 1e-2))   # (key.bias: analytically zero, absolute scale)
+        cos.append(float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)))
+        ratio.append(float(a.norm()) / (nb + 1e-30))
+    return names, np.array(rel), np.array(cos), np.array(ratio)
+
+
+def shape_true_bf16_case(name, sm, pre, cfg: orc.OracleConfig, B, seed):
+    """G16 (round 4): the REFERENCE's own reduced-precision gradients at the real shape. Same weights, table and batch as
+    g3_shapetrue (same seeds); the reference's forward runs once in fp32 and once under torch.autocast(bf16) - the
+    mixed precision a CPU offers; the reference trains with fp16=True (ref:stonkgs_pretraining.py:178) - and both are
+    back-propagated. Stored per gradient tensor: the relative L2 error, cosine and norm ratio of the autocast gradient
+    against the fp32 one - the deviation the reference's own mixed-precision backward shows, which the HIP path's
+    per-tensor gradient error is held to - plus both losses and the autocast gradients on g3's sampled slices."""
+    sd = orc.init_state_dict(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    tsv_rows = torch.randn(cfg.kg_vocab_size, cfg.hidden_size, generator=g, dtype=torch.float64) * 0.3
+    model = build_reference_model(sm, cfg, sd, tsv_rows)
+    batch = make_batch(cfg, B, seed + 2, pre)
+    grads, losses = {}, {}
+    for mode in ("fp32", "bf16_autocast"):
+        model.zero_grad()
+        if mode == "fp32":
+            out = model(**batch, return_dict=True)
+        else:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out = model(**batch, return_dict=True)
+        out.loss.float().backward()
+        losses[mode] = float(out.loss)
+        grads[mode] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    names, rel, cos, ratio = _grad_envelope(grads["fp32"], grads["bf16_autocast"])
+    arrays = {"loss_fp32": np.float64(losses["fp32"]), "loss_bf16_autocast": np.float64(losses["bf16_autocast"]),
+              "grad_relerr_bf16": rel, "grad_cosine_bf16": cos, "grad_norm_ratio_bf16": ratio}
+    with open(os.path.join(OUT, "g3_shapetrue.json")) as f:
+        g3 = json.load(f)
+    assert g3["grad_names"] == names, "g16 must list g3's gradient tensors in g3's order"
+    for k, spec in g3["grad_slices"].items():
+        sl = tuple(slice(a, b, c) for a, b, c in spec)
+        arrays["grad_s_bf16::" + k] = grads["bf16_autocast"][k][sl].float().numpy()
+    meta = {"same_case_as": "g3_shapetrue", "B": B, "weight_seed": seed, "table_seed": seed + 1, "batch_seed": seed + 2,
+            "grad_names": names, "autocast": "torch.autocast('cpu', dtype=torch.bfloat16) around the forward",
+            "summary": {"relerr_max": float(rel.max()), "relerr_median": float(np.median(rel)),
+                        "cosine_min": float(cos.min())}, "torch": torch.__version__}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(name, "loss fp32", losses["fp32"], "bf16", losses["bf16_autocast"], "| reference bf16 gradient error per tensor: max",
+          rel.max(), "median", np.median(rel), "min cosine", cos.min())
+
+
+def classification_bf16_case(name, sm, ft, pre, cfg: orc.OracleConfig, B, seed, num_labels):
+    """G17 (round 4): BASELINE config 5 at the real depth - the reference's STonKGsForSequenceClassification
+    (ref:stonkgs_finetuning.py:237-346) at 12L / 768h / 12 heads / S 512 on a ragged batch of three, forward + backward in
+    fp32 and under torch.autocast(bf16). Stored: the batch, labels, loss and logits of both runs, the fp32 gradient norm of
+    every tensor, sampled fp32 gradient slices, and the per-tensor error of the reference's own reduced-precision backward."""
+    from transformers import BertConfig, BertForPreTraining, BertModel
+
+    sd = orc.init_state_dict(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    tsv_rows = torch.randn(cfg.kg_vocab_size, cfg.hidden_size, generator=g, dtype=torch.float64) * 0.3
+    gw = torch.Generator().manual_seed(seed + 3)
+    sd["classifier.weight"] = (torch.randn(num_labels, cfg.hidden_size, generator=gw) * 0.02).to(torch.bfloat16).float()
+    sd["classifier.bias"] = (torch.randn(num_labels, generator=gw) * 0.02).to(torch.bfloat16).float()
+    hf_cfg = BertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+                        num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                        intermediate_size=cfg.intermediate_size, max_position_embeddings=cfg.max_position_embeddings,
+                        type_vocab_size=cfg.type_vocab_size, layer_norm_eps=cfg.layer_norm_eps,
+                        hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, attn_implementation="eager",
+                        num_labels=num_labels)
+    hf_cfg.update({"kg_vocab_size": cfg.kg_vocab_size})
+
+    class RefCls(ft.STonKGsForSequenceClassification):  # forward is the reference's; only the hub-fetching init is not
+        def __init__(self, c):
+            BertForPreTraining.__init__(self, c)
+            self.cls.predictions = sm.STonKGsELMPredictionHead(c)
+            self.lm_backbone = BertModel(c)
+            for p in self.lm_backbone.parameters():
+                p.requires_grad = False
+            self.lm_sep_id, self.lm_mask_id, self.lm_unk_id = 102, 103, 100
+            self.num_labels = c.num_labels
+            self.config = c
+            self.bert = BertModel(c)
+            self.dropout = torch.nn.Dropout(c.hidden_dropout_prob)
+            self.classifier = torch.nn.Linear(c.hidden_size, c.num_labels)
+
+    model = RefCls(hf_cfg)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(("position_ids" in k or "decoder" in k) for k in missing), (missing, unexpected)
+    model.eval()
+    K = cfg.kg_vocab_size
+    numeric_indices = [i for i in range(K + 3) if i not in (102, 103, 100)]
+    model.kg_backbone = {i: torch.tensor(tsv_rows[r].numpy()) for r, i in enumerate(numeric_indices)}
+    with torch.no_grad():
+        for sid in (102, 103, 100):
+            model.kg_backbone[sid] = model.lm_backbone(torch.tensor([[sid]]))[0][0][0]
+    batch = make_batch(cfg, B, seed + 2, pre)
+    labels = torch.tensor(np.random.RandomState(seed + 4).randint(0, num_labels, B))
+    inputs = {k: batch[k] for k in ("input_ids", "attention_mask", "token_type_ids")}
+    grads, res = {}, {}
+    for mode in ("fp32", "bf16_autocast"):
+        model.zero_grad()
+        if mode == "fp32":
+            out = model(**inputs, labels=labels, return_dict=True)
+        else:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out = model(**inputs, labels=labels, return_dict=True)
+        out.loss.float().backward()
+        res[mode] = (float(out.loss), out.logits.detach().float().numpy())
+        grads[mode] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    names, rel, cos, ratio = _grad_envelope(grads["fp32"], grads["bf16_autocast"])
+    arrays = {k: v.numpy() for k, v in inputs.items()}
+    arrays.update(labels=labels.numpy(), loss_fp32=np.float64(res["fp32"][0]), logits_fp32=res["fp32"][1],
+                  loss_bf16_autocast=np.float64(res["bf16_autocast"][0]), logits_bf16_autocast=res["bf16_autocast"][1],
+                  grad_norms=np.array([float(grads["fp32"][k].double().norm()) for k in names]),
+                  grad_relerr_bf16=rel, grad_cosine_bf16=cos, grad_norm_ratio_bf16=ratio)
+    L = cfg.num_hidden_layers
+    slices = {"classifier.weight": (slice(None), slice(None)),
+              "bert.pooler.dense.weight": (slice(None, None, 16), slice(None, None, 16)),
+              f"bert.encoder.layer.{L - 1}.output.dense.weight": (slice(None, None, 16), slice(None, None, 64)),
+              f"bert.encoder.layer.{L - 1}.attention.self.query.weight": (slice(None, None, 16), slice(None, None, 16)),
+              "bert.encoder.layer.0.intermediate.dense.weight": (slice(None, None, 64), slice(None, None, 16)),
+              "bert.embeddings.position_embeddings.weight": (slice(None, None, 8), slice(None, None, 16))}
+    for k, sl in slices.items():
+        arrays["grad_s::" + k] = grads["fp32"][k][sl].numpy()
+        arrays["grad_s_bf16::" + k] = grads["bf16_autocast"][k][sl].float().numpy()
+    meta = {"config": {k: getattr(cfg, k) for k in ("vocab_size", "kg_vocab_size", "hidden_size", "num_hidden_layers",
+                                                    "num_attention_heads", "intermediate_size",
+                                                    "max_position_embeddings", "type_vocab_size", "layer_norm_eps")},
+            "B": B, "weight_seed": seed, "table_seed": seed + 1, "batch_seed": seed + 2, "classifier_seed": seed + 3,
+            "label_seed": seed + 4, "num_labels": num_labels, "table_std": 0.3, "grad_names": names,
+            "grad_keys": list(slices), "grad_slices": {k: [[x.start, x.stop, x.step] for x in sl] for k, sl in slices.items()},
+            "weights_checksum": float(sum(v.double().abs().sum() for k, v in sd.items() if not k.startswith("classifier"))),
+            "table_checksum": float(tsv_rows.abs().sum()),
+            "summary": {"relerr_max": float(rel.max()), "relerr_median": float(np.median(rel)), "cosine_min": float(cos.min())},
+            "torch": torch.__version__}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    with open(os.path.join(OUT, name + ".json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(name, "loss fp32", res["fp32"][0], "bf16", res["bf16_autocast"][0], "| reference bf16 gradient error per tensor: max",
+          rel.max(), "median", np.median(rel), "min cosine", cos.min())
+
+
 def curve_case(name, sm, pre, cfg: orc.OracleConfig, B, seed, steps, lr, n_batches):
     """G11/G12: the REFERENCE's loss curve and the reference's own mixed-precision envelope. The reference model (its own
     forward, HF BERT, torch AdamW, clip 1.0, linear schedule: ref:src/stonkgs/models/stonkgs_pretraining.py:171-223 ->
@@ -650,6 +799,18 @@ def main():
         classification_case("g13_cls_regression_1d", sm, ft, pre, small, B=5, seed=310, num_labels=1, problem="regression_1d")
         classification_case("g14_cls_regression", sm, ft, pre, small, B=4, seed=320, num_labels=3, problem="regression")
         classification_case("g15_cls_multilabel", sm, ft, pre, small, B=6, seed=330, num_labels=3, problem="multi_label")
+        return
+    if only == "bf16_grads":   # round 4: the reference's own reduced-precision gradients at the real shape (minutes of CPU)
+        torch.set_num_threads(8)
+        shape_true_bf16_case("g16_shapetrue_bf16", sm, pre, orc.OracleConfig(kg_vocab_size=4096), B=2, seed=500)
+        classification_bf16_case("g17_cls_shapetrue", sm, import_reference_finetuning(), pre,
+                                 orc.OracleConfig(kg_vocab_size=1000), B=3, seed=900, num_labels=2)
+        return
+    if only == "cls":   # only g6 (its metadata keys were added after the first write)
+        classification_case("g6_classification", sm, import_reference_finetuning(), pre,
+                            orc.OracleConfig(vocab_size=512, kg_vocab_size=300, hidden_size=128, num_hidden_layers=2,
+                                             num_attention_heads=2, intermediate_size=256, max_position_embeddings=256),
+                            B=5, seed=300, num_labels=3)
         return
     if only in ("shape", "f3"):   # (re)generate only the round-2 cases
         if only == "shape":

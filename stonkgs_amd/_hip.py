@@ -26,6 +26,7 @@ EPI_GELU_BWD = 1 << 6
 EPI_DROPOUT = 1 << 7
 EPI_AUX_GRAD = 1 << 8   # aux = gelu'(pre-activation): stored by SAVE_PREACT (with GELU), multiplied in by GELU_BWD
 GEMM_AUTO, GEMM_TILE128, GEMM_WAVE8, GEMM_WAVE4, GEMM_WAVE4_192, GEMM_DISPATCHED, GEMM_DISPATCHED2 = 0, 1, 2, 3, 4, 5, 6   # stonk_gemm_nt_bf16 `kernel`
+GEMM_ASM4, GEMM_ASM4_192 = 7, 8   # the written-out four-wave kernel (gemm_a4.hip), 256x256 / 256x192 tiles
 LN_DROPOUT = 1 << 0
 SMALL_TANH = 1
 SMALL_X_F32 = 16

@@ -1,0 +1,340 @@
+// bf16 MFMA GEMM, 256 x (256 | 192) x 64 tiles, FOUR waves per workgroup (one per SIMD, 128 x 128 | 96 wave tiles),
+// v_mfma_f32_16x16x32_bf16, operands by LDS-DMA (buffer_load ... lds), and a K loop whose instruction stream is
+// WRITTEN OUT: tools/gen_gemm_a4.py generates gemm_a4_loop.inc, one inline-assembly block per output tile.
+// Same contract as gemm_bf16.hip (C = epilogue(alpha * A[M,K] . B[N,K]^T)), bf16 output, no K split.
+//
+// Why a fourth NT kernel: gemm_w4.hip has this geometry in compiled C++ and keeps the matrix pipe
+// 54-64 % busy - with one wave per SIMD every instruction that is not in an MFMA's shadow delays the next MFMA, and the
+// compiler's scheduler, register staging (global -> VGPR -> ds_write) and 32x32x16 MFMAs (a lower clock under load than
+// 16x16x32 at equal cycles: the guide's DVFS note) are what separated it from the vendor library's 93 %. Here:
+//  * accumulators live in a[0:255] (the AGPR half of the unified file), fragments in v[128:255], the compiler keeps
+//    v[0:127] for everything else - nothing is ever spilled inside the loop because the compiler does not own the loop;
+//  * operands go global -> LDS directly (no staging registers, no ds_write), two K tiles ahead, and across output tiles:
+//    the last two K tiles of a tile request the first two of the workgroup's NEXT tile, so the epilogue runs with the
+//    next K loop's operands already on their way;
+//  * every wait of the loop is "all but this K tile's own pieces" (s_waitcnt vmcnt(pieces)), so whatever else is older
+//    in the queue - the previous tile's output stores, side-operand loads - can only strengthen a wait;
+//  * the epilogue needs no LDS: a v_permlane16_swap per register pair turns the 16x16 accumulator layout (a lane = one
+//    row, 4 consecutive columns per block) into 8 consecutive columns per lane, i.e. 16-byte stores and 16-byte side
+//    operand loads (residual, saved GELU') at the same addresses, requested a row block ahead.
+#include "gemm_common.h"
+#include "gemm_a4_loop.inc"
+
+using namespace stonk_gemm;
+
+namespace {
+
+constexpr int BM = 256, BK = 64;
+constexpr int IMG_BYTES = 256 * BK * 2;       // one operand image of one K tile: 32 KiB
+constexpr int LDS_BYTES = 4 * IMG_BYTES;      // two stages x (A image + B image) = 128 KiB
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+struct Work {
+  int m0, n0;
+};
+
+template <int EPI, int BN_>
+__global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
+  static_assert(BN_ == 256 || BN_ == 192, "tile widths: 256 or 192");
+  constexpr int BN = BN_;
+  constexpr int NBJ = BN_ / 32;       // 16-column blocks per wave
+  constexpr int NPB = BN_ / 32;       // 8-row pieces of the B image per wave and K tile
+  constexpr int BROWS_W = BN_ / 4;    // rows of the B image each wave stages
+  constexpr int NACC = 2 * NBJ;       // accumulator registers in units of 16
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  int M = p.M;
+  if (p.m_dev) {
+    const int md = *p.m_dev;
+    M = md < M ? md : M;
+  }
+  const int N = p.N;
+  const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+  const int nk = p.K / BK;            // even, >= 2 (launcher)
+  const int total = ntm * ntn;
+  const int G = gridDim.x;
+
+  // work item -> tile; the items of one round that the workgroups of one XCD take are neighbours (as gemm_w4.hip)
+  auto get_work = [&](int w, Work& o) -> bool {
+    if (w >= total) return false;
+    int idx = w;
+    if ((G & 7) == 0) {
+      const int r = w / G, b = w - r * G;
+      const int n_r = total - r * G < G ? total - r * G : G;
+      const int x = b & 7, s = b >> 3, q = n_r >> 3, rem = n_r & 7;
+      if (s >= q + (x < rem ? 1 : 0)) return false;
+      idx = r * G + x * q + (x < rem ? x : rem) + s;
+    }
+    int rt, ct;
+    if (ntm >= ntn) {
+      rt = idx / ntn;
+      ct = idx - rt * ntn;
+    } else {
+      ct = idx / ntm;
+      rt = idx - ct * ntm;
+    }
+    o.m0 = rt * BM;
+    o.n0 = ct * BN;
+    return true;
+  };
+
+  // ---- LDS-DMA sources. Piece q of this wave = image rows 8 q .. 8 q + 7 of its 64 (A) / BROWS_W (B) rows; a lane moves
+  // 16 bytes: image row l8 = lane >> 3, PHYSICAL chunk lane & 7, i.e. logical chunk (lane & 7) ^ ((row >> 1) & 7) - the
+  // LDS image is lane-linear (the DMA's destination is M0 + 16 lane), the swizzle is on the source. One per-lane byte
+  // offset per piece; the buffer's base is the tile's first row at the K tile's first column and its extent what is left
+  // of the operand from there, so rows past the operand's end are out of range and arrive as zeros (the range check
+  // covers the per-lane offset only - nothing rides in the scalar offset).
+  const int l8 = lane >> 3;
+  const int lda2 = (int)p.lda * 2, ldb2 = (int)p.ldb * 2;
+  int voffA[8], voffB[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int c = (((lane & 7) ^ (l8 >> 1) ^ (4 * (q & 1))) << 4);
+    voffA[q] = (wave * 64 + 8 * q + l8) * lda2 + c;
+    voffB[q] = (wave * BROWS_W + 8 * (q < NPB ? q : 0) + l8) * ldb2 + c;
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int m0a = (int)lds0 + wave * 8192;
+  const int m0b = (int)lds0 + 2 * IMG_BYTES + wave * (BROWS_W * 128);
+  // ---- fragment reads: lane (r = lane & 15, qq = lane >> 4) takes row r of a 16-row block, k = 32 h + 8 qq .. +7
+  const int r16 = lane & 15, qq = lane >> 4;
+  int raA[2], raB[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int o = r16 * 128 + ((((4 * h + qq) ^ (r16 >> 1)) & 7) << 4);
+    raA[h] = (int)lds0 + wr * 16384 + o;
+    raB[h] = (int)lds0 + 2 * IMG_BYTES + wc * (BN_ / 2) * 128 + o;
+  }
+
+  auto cursor_of = [&](const Work& w, i32x4& a, i32x4& b) {
+    const unsigned long pa = (unsigned long)p.A + (unsigned long)((long)w.m0 * lda2);
+    const unsigned long pb = (unsigned long)p.B + (unsigned long)((long)w.n0 * ldb2);
+    a = (i32x4){(int)(unsigned)pa, (int)((pa >> 32) & 0xffff), (M - w.m0) * lda2, 0x00020000};
+    b = (i32x4){(int)(unsigned)pb, (int)((pb >> 32) & 0xffff), (N - w.n0) * ldb2, 0x00020000};
+  };
+
+  Work cw, nw;
+  int cwi = blockIdx.x;
+  if (!get_work(cwi, cw)) return;     // uniform: whole workgroup leaves together
+  i32x4 curA, curB;                   // the operand cursors (s[36:39], s[40:43] inside the blocks)
+  cursor_of(cw, curA, curB);
+
+#define STONK_A4_VOFF_OPERANDS                                                                                          \
+  [voffA0] "v"(voffA[0]), [voffA1] "v"(voffA[1]), [voffA2] "v"(voffA[2]), [voffA3] "v"(voffA[3]), [voffA4] "v"(voffA[4]), \
+      [voffA5] "v"(voffA[5]), [voffA6] "v"(voffA[6]), [voffA7] "v"(voffA[7]), [voffB0] "v"(voffB[0]),                   \
+      [voffB1] "v"(voffB[1]), [voffB2] "v"(voffB[2]), [voffB3] "v"(voffB[3]), [voffB4] "v"(voffB[4]),                   \
+      [voffB5] "v"(voffB[5]), [voffB6] "v"(voffB[6]), [voffB7] "v"(voffB[7]), [m0a] "s"(m0a), [m0b] "s"(m0b)
+
+  // K tiles 0 and 1 of the first tile
+  if (BN_ == 256)
+    asm volatile(STONK_A4_PROLOGUE_256 : "+{s[36:39]}"(curA), "+{s[40:43]}"(curB) : STONK_A4_VOFF_OPERANDS : "m0", "scc", "memory");
+  else
+    asm volatile(STONK_A4_PROLOGUE_192 : "+{s[36:39]}"(curA), "+{s[40:43]}"(curB) : STONK_A4_VOFF_OPERANDS : "m0", "scc", "memory");
+
+  const int flags = EPI;
+  const int ldc_b = (int)p.ldc * 2, ldr_b = (int)p.ldr * 2, ldx_b = (int)p.ldaux * 2;
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, M * ldc_b, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, M * ldr_b, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.aux, 0, M * ldx_b, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, N * 4, 0x00020000);
+  constexpr bool SIDE_X = (EPI & STONK_EPI_GELU_BWD) != 0;
+  constexpr bool SIDE_R = (EPI & STONK_EPI_RESID) != 0;
+  static_assert(!(SIDE_X && SIDE_R), "one side operand per launch");
+  constexpr bool SIDE = SIDE_X || SIDE_R;
+  constexpr int NJP = NBJ / 2;        // pairs of column blocks = 16-byte pieces per lane and row block
+  // a lane's 8 output columns of pair jp: the pair's first block for even qq, its second for odd qq; halves by qq >> 1
+  const int ncol = wc * (BN_ / 2) + 16 * (qq & 1) + 8 * (qq >> 1);
+
+  for (;;) {
+    const bool more = get_work(cwi + G, nw);
+    i32x4 nxA, nxB;
+    cursor_of(more ? nw : cw, nxA, nxB);   // (no next tile: the cursor re-reads this tile's first K tiles, never consumed)
+    f32x16 acc[16];
+    int rem = nk >> 1;
+    // the bias of this lane's columns: requested before the K loop, used after it
+    f32x4 bq[NJP][2];
+    if (flags & STONK_EPI_BIAS) {
+#pragma unroll
+      for (int jp = 0; jp < NJP; ++jp)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          bq[jp][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBias, (cw.n0 + ncol + 32 * jp + 4 * h) * 4, 0, 0));
+    }
+#define STONK_A4_TILE_OPERANDS                                                                                        \
+  STONK_A4_VOFF_OPERANDS, [raA0] "v"(raA[0]), [raA1] "v"(raA[1]), [raB0] "v"(raB[0]), [raB1] "v"(raB[1]),             \
+      [nal] "s"(nxA[0]), [nah] "s"(nxA[1]), [nan] "s"(nxA[2]), [nbl] "s"(nxB[0]), [nbh] "s"(nxB[1]), [nbn] "s"(nxB[2])
+#define STONK_A4_CLOBBERS                                                                                              \
+  "m0", "scc", "memory", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", \
+      "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153",  \
+      "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167",  \
+      "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181",  \
+      "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195",  \
+      "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209",  \
+      "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223",  \
+      "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237",  \
+      "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251",  \
+      "v252", "v253", "v254", "v255"
+    if (BN_ == 256) {
+      asm volatile(STONK_A4_TILE_256
+                   : "={a[0:15]}"(acc[0]), "={a[16:31]}"(acc[1]), "={a[32:47]}"(acc[2]), "={a[48:63]}"(acc[3]),
+                     "={a[64:79]}"(acc[4]), "={a[80:95]}"(acc[5]), "={a[96:111]}"(acc[6]), "={a[112:127]}"(acc[7]),
+                     "={a[128:143]}"(acc[8]), "={a[144:159]}"(acc[9]), "={a[160:175]}"(acc[10]), "={a[176:191]}"(acc[11]),
+                     "={a[192:207]}"(acc[12]), "={a[208:223]}"(acc[13]), "={a[224:239]}"(acc[14]), "={a[240:255]}"(acc[15]),
+                     "+{s[36:39]}"(curA), "+{s[40:43]}"(curB), [rem] "+s"(rem)
+                   : STONK_A4_TILE_OPERANDS
+                   : STONK_A4_CLOBBERS);
+    } else {
+      asm volatile(STONK_A4_TILE_192
+                   : "={a[0:15]}"(acc[0]), "={a[16:31]}"(acc[1]), "={a[32:47]}"(acc[2]), "={a[48:63]}"(acc[3]),
+                     "={a[64:79]}"(acc[4]), "={a[80:95]}"(acc[5]), "={a[96:111]}"(acc[6]), "={a[112:127]}"(acc[7]),
+                     "={a[128:143]}"(acc[8]), "={a[144:159]}"(acc[9]), "={a[160:175]}"(acc[10]), "={a[176:191]}"(acc[11]),
+                     "+{s[36:39]}"(curA), "+{s[40:43]}"(curB), [rem] "+s"(rem)
+                   : STONK_A4_TILE_OPERANDS
+                   : STONK_A4_CLOBBERS);
+    }
+
+    // (the accumulators stay where they are - AGPR-class values - until the epilogue reads them one by one: copied out
+    // wholesale into VGPRs after the block they would push everything that lives across the K loop into scratch)
+#pragma unroll
+    for (int g = 0; g < NACC; ++g) asm volatile("" : "+a"(acc[g]));
+    // ---- epilogue: row block i (16 rows: a lane's row is r16), column-block pair jp -> 8 consecutive columns per lane
+    const int wm0 = cw.m0 + wr * 128, wn0 = cw.n0 + ncol;
+    bf16x8 sd[NJP];
+    auto side_request = [&](const int i) {
+      if (!SIDE) return;
+      const int m = wm0 + 16 * i + r16;
+#pragma unroll
+      for (int jp = 0; jp < NJP; ++jp) {
+        const int n = wn0 + 32 * jp;
+        const int oob = n < N ? 0 : 0x40000000;
+        sd[jp] = __builtin_bit_cast(bf16x8, SIDE_X ? __builtin_amdgcn_raw_buffer_load_b128(rX, m * ldx_b + n * 2 + oob, 0, 0)
+                                                  : __builtin_amdgcn_raw_buffer_load_b128(rR, m * ldr_b + n * 2 + oob, 0, 0));
+      }
+    };
+    side_request(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = wm0 + 16 * i + r16;
+      bf16x8 cur[NJP];
+#pragma unroll
+      for (int jp = 0; jp < NJP; ++jp) cur[jp] = sd[jp];
+      if (i + 1 < 8) side_request(i + 1);   // flies while this row block is processed
+#pragma unroll
+      for (int jp = 0; jp < NJP; ++jp) {
+        const int bx = NBJ * i + 2 * jp, by = bx + 1;   // accumulator blocks (i, 2 jp) and (i, 2 jp + 1)
+        // rows of 16 lanes: x's odd rows <-> y's even rows. Afterwards (x, y) of a lane are columns 0-3 / 4-7 of its 8
+        // consecutive output columns. (Inline assembly: this toolchain's __builtin_amdgcn_permlane16_swap returns its
+        // FIRST result twice. The no-ops stand in for the VALU <-> permlane wait states the compiler would have placed.)
+        float x0 = acc[bx >> 2][4 * (bx & 3) + 0], x1 = acc[bx >> 2][4 * (bx & 3) + 1], x2 = acc[bx >> 2][4 * (bx & 3) + 2],
+              x3 = acc[bx >> 2][4 * (bx & 3) + 3];
+        float y0 = acc[by >> 2][4 * (by & 3) + 0], y1 = acc[by >> 2][4 * (by & 3) + 1], y2 = acc[by >> 2][4 * (by & 3) + 2],
+              y3 = acc[by >> 2][4 * (by & 3) + 3];
+        asm volatile("s_nop 1\n"
+                     "v_permlane16_swap_b32 %0, %4\n"
+                     "v_permlane16_swap_b32 %1, %5\n"
+                     "v_permlane16_swap_b32 %2, %6\n"
+                     "v_permlane16_swap_b32 %3, %7\n"
+                     "s_nop 1"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
+        float v[8] = {x0 * p.alpha, x1 * p.alpha, x2 * p.alpha, x3 * p.alpha, y0 * p.alpha, y1 * p.alpha, y2 * p.alpha, y3 * p.alpha};
+        const int n = wn0 + 32 * jp;
+        const int oob = n < N ? 0 : 0x40000000;   // columns past N: pushed out of the buffers' range
+        if (flags & STONK_EPI_BIAS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] += bq[jp][0][e];
+            v[4 + e] += bq[jp][1][e];
+          }
+        }
+        if (flags & STONK_EPI_SAVE_PREACT) {
+          bf16x8 u;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) u[e] = (bf16)gelu_saved(v[e], (flags & STONK_EPI_AUX_GRAD) != 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, u), rX, m * ldx_b + n * 2 + oob, 0, 0);
+        }
+        SideOps so;
+        so.aux = so.res = cur[jp];
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        epilogue8_pre(v, p, flags & ~(STONK_EPI_BIAS | STONK_EPI_SAVE_PREACT), m, n, z4, z4, so);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rC, m * ldc_b + n * 2 + oob, 0, 0);
+      }
+    }
+    if (!more) break;
+    cwi += G;
+    cw = nw;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the cursor's last, unused pieces
+#undef STONK_A4_TILE_OPERANDS
+#undef STONK_A4_VOFF_OPERANDS
+#undef STONK_A4_CLOBBERS
+}
+
+template <int EPI, int BN_>
+int launch_a4(const GemmArgs& a, int grid, hipStream_t st) {
+  static bool attr_done = false;   // (one process per GPU: the attribute is per function and device)
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_a4_kernel<EPI, BN_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_a4_kernel<EPI, BN_>), dim3(grid), dim3(256), LDS_BYTES, st, a);
+  return stonk_launch_status();
+}
+
+}  // namespace
+
+// Launcher used by stonk_gemm_nt_bf16 (gemm_bf16.hip). Requires bf16 output, split_k == 1, K % 128 == 0, ld % 64 == 0,
+// 32-bit operand extents, 16-byte aligned side operands. tile_n: 0 = choose, 256, 192. items_per_wg as gemm_w4.hip.
+// Returns STONK_ESHAPE for an epilogue this kernel has no instance of (the caller then takes another kernel).
+int stonk_gemm_a4_launch(const GemmArgs& a, int tile_n, int items_per_wg, hipStream_t st) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipGetLastError();
+    n_cu = prop.multiProcessorCount;
+  }
+  constexpr int B = STONK_EPI_BIAS, G = STONK_EPI_GELU, SV = STONK_EPI_SAVE_PREACT, GB = STONK_EPI_GELU_BWD,
+                R = STONK_EPI_RESID, D = STONK_EPI_DROPOUT, AG = STONK_EPI_AUX_GRAD;
+  const int epi = a.flags & (B | G | SV | GB | R | D | AG);
+  const long ntm = (a.M + BM - 1) / BM;
+  const bool has192 = a.N % 192 == 0 && (epi == 0 || epi == B || epi == R || epi == (B | R) || epi == (B | R | D));
+  if (tile_n == 192 && !has192) return STONK_ESHAPE;
+  if (tile_n == 0) {
+    const long t256 = ntm * ((a.N + 255) / 256), t192 = ntm * (a.N / 192);
+    const long c256 = ((t256 + n_cu - 1) / n_cu) * 256, c192 = ((t192 + n_cu - 1) / n_cu) * 192;
+    tile_n = (has192 && c192 < c256) ? 192 : 256;
+  }
+  const long tiles = tile_n == 192 ? ntm * (a.N / 192) : ntm * ((a.N + 255) / 256);
+  const int grid = (int)(items_per_wg > 0 ? (tiles + items_per_wg - 1) / items_per_wg : (tiles < n_cu ? tiles : n_cu));
+  if (tile_n == 192) {
+    switch (epi) {
+      case 0: return launch_a4<0, 192>(a, grid, st);
+      case B: return launch_a4<B, 192>(a, grid, st);
+      case R: return launch_a4<R, 192>(a, grid, st);
+      case B | R: return launch_a4<B | R, 192>(a, grid, st);
+      default: return launch_a4<B | R | D, 192>(a, grid, st);
+    }
+  }
+  switch (epi) {
+    case 0: return launch_a4<0, 256>(a, grid, st);
+    case B: return launch_a4<B, 256>(a, grid, st);
+    case B | G: return launch_a4<B | G, 256>(a, grid, st);
+    case B | G | SV: return launch_a4<B | G | SV, 256>(a, grid, st);
+    case GB: return launch_a4<GB, 256>(a, grid, st);
+    case B | G | SV | AG: return launch_a4<B | G | SV | AG, 256>(a, grid, st);
+    case GB | AG: return launch_a4<GB | AG, 256>(a, grid, st);
+    case R: return launch_a4<R, 256>(a, grid, st);
+    case B | R: return launch_a4<B | R, 256>(a, grid, st);
+    case B | R | D: return launch_a4<B | R | D, 256>(a, grid, st);
+    default: return STONK_ESHAPE;
+  }
+}

@@ -22,6 +22,7 @@ using namespace stonk_gemm;
 // defined in gemm256.hip
 int stonk_gemm256_launch(const GemmArgs& a, int out_mode, hipStream_t st);
 int stonk_gemm_w4_launch(const GemmArgs& a, int out_mode, int tile_n, int items_per_wg, hipStream_t st);
+int stonk_gemm_a4_launch(const GemmArgs& a, int tile_n, int items_per_wg, hipStream_t st);
 
 namespace {
 
@@ -302,7 +303,7 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
                                   const int* m_dev, const int* k_dev, float drop_p, uint32_t seed, int kernel,
                                   void* stream) {
   STONK_CHECK_ARG(A && B && C, STONK_EINVAL);
-  STONK_CHECK_ARG(kernel >= STONK_GEMM_AUTO && kernel <= STONK_GEMM_DISPATCHED2, STONK_EINVAL);
+  STONK_CHECK_ARG(kernel >= STONK_GEMM_AUTO && kernel <= STONK_GEMM_ASM4_192, STONK_EINVAL);
   STONK_CHECK_ARG(M >= 0 && N > 0 && K > 0, STONK_ESHAPE);
   STONK_CHECK_ARG(N % BN == 0 && K % BK == 0, STONK_ESHAPE);
   STONK_CHECK_ARG(split_k >= 1 && split_k <= K / BK, STONK_ESHAPE);
@@ -376,6 +377,12 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
         // has 256x192 tiles: 42.6 against 52.3 us (tools/bench_w4_tiles.py)
         : (w4_ok && M >= 1024 && N % 192 == 0 && out_mode == STONK_EPI_OUT_BF16 && (flags & 0x1FC) == 0) ? STONK_GEMM_WAVE4
                                                                              : STONK_GEMM_TILE128;
+  // the written-out four-wave kernel (gemm_a4.hip): bf16 output, no K split, no device-side K, one side operand at most
+  const bool a4_ok = w4_ok && out_mode == STONK_EPI_OUT_BF16 && split_k == 1 && (K / BK) >= 2;
+  if (k == STONK_GEMM_ASM4 || k == STONK_GEMM_ASM4_192) {
+    STONK_CHECK_ARG(a4_ok, STONK_ESHAPE);
+    return stonk_gemm_a4_launch(a, k == STONK_GEMM_ASM4 ? 256 : 192, 0, st);
+  }
   if (k == STONK_GEMM_WAVE4 || k == STONK_GEMM_WAVE4_192) {
     STONK_CHECK_ARG(w4_ok, STONK_ESHAPE);
     // chosen by AUTO: the launcher also picks the tile width (256x192 where N = 768 / 2304 quantise better on 256 CUs)

@@ -31,6 +31,9 @@
                                  launch beside which another stream (a collective) holds CUs: a persistent grid with a static tile \
                                  split waits for its last workgroup to get a CU */
 #define STONK_GEMM_DISPATCHED2 6 /* the same with TWO work items per workgroup (grid = tiles / 2): every second tile boundary                                  keeps its prefetch, the dispatcher still hands out the work in pieces far smaller than a                                  CU's share; where DISPATCHED runs 128x128 tiles this is DISPATCHED */
+#define STONK_GEMM_ASM4 7     /* persistent 256x256x64, four waves, 16x16x32 MFMAs, LDS-DMA operands, the K loop a written-out \
+                                 instruction stream (gemm_a4.hip): bf16 output, split_k == 1, the step's epilogues */
+#define STONK_GEMM_ASM4_192 8 /* the same on 256x192 tiles: N % 192 == 0, the epilogues of the N = 768 launches */
 // --- stonk_layernorm_* `flags` ---
 #define STONK_LN_DROPOUT (1 << 0)
 // --- stonk_small_linear_* `act` ---

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Generates stonkgs_amd/csrc/gemm_a4_loop.inc: the instruction stream of the K loop of the four-wave NT GEMM
+(gemm_a4.hip) as inline-assembly string literals, one set per tile width.
+
+Why generated text and not C++: with one wave per SIMD the matrix pipe is busy only while the wave's single
+instruction stream presents an MFMA every 16 cycles, and hipcc's scheduler would not keep the LDS reads, LDS-DMA
+issues and scalar bookkeeping inside the MFMA shadows (gemm_w4.hip, compiled C++: 54-64 % of the pipe's cycles). Here
+every instruction of the loop has its place; the schedule is DATA in this script (which gap after which MFMA carries
+which memory instruction) and can be re-tuned without touching the kernel.
+
+The pipeline:
+  wave tile 128 x (16 NBJ), v_mfma_f32_16x16x32_bf16, accumulators a[0 : 32 NBJ), fragments in v[128:255] (two sets);
+  K tile t lives in LDS stage t & 1 (A image 256 rows x 128 B, B image BN rows x 128 B, XOR-swizzled rows);
+  phase 1 of a K tile multiplies k-half 0 (set 0) while reading k-half 1 (set 1) from the same stage; once every wave has
+  read the stage dry - lgkmcnt(0), barrier B1 - the LDS-DMA of K tile t+2 into THAT stage starts (buffer_load ... lds,
+  M0 = destination); phase 2 multiplies k-half 1 while the rest of those pieces are issued; then vmcnt(pieces) retires
+  K tile t+1 (issued one K tile earlier), barrier B2, and k-half 0 of K tile t+1 is read from the other stage into set 0.
+  Every wait is "all but this K tile's pieces", so anything older - the previous tile's stores included - only makes a
+  wait stronger, never weaker. Two barriers per K tile; the operand stream runs two K tiles ahead and across output tiles.
+"""
+import os
+import sys
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "stonkgs_amd", "csrc", "gemm_a4_loop.inc")
+
+IMG = 32768          # one operand image of one stage
+B_BASE = 65536       # B images behind the two A images
+
+
+class Cfg:
+    def __init__(self, nbj):
+        self.nbj = nbj                 # 16-column blocks per wave
+        self.bn = 32 * nbj             # tile width (two wave columns)
+        self.npb = self.bn // 32       # B pieces (8 rows x 128 B) per wave and K tile
+        self.ndma = 8 + self.npb
+        self.nm = 8 * nbj              # MFMAs per phase
+        self.tag = str(self.bn)
+
+
+def acc(c, i, j):
+    b = 4 * (c.nbj * i + j)
+    return f"a[{b}:{b + 3}]"
+
+
+def fa(s, i):
+    b = 128 + 64 * s + 4 * i
+    return f"v[{b}:{b + 3}]"
+
+
+def fb(s, j):
+    b = 160 + 64 * s + 4 * j
+    return f"v[{b}:{b + 3}]"
+
+
+def mfma(c, h, i, j, first):
+    cc = "0" if first else acc(c, i, j)
+    # D[n][m]: srcA = the weight fragment (rows n), srcB = the activation fragment (rows m): a lane then holds
+    # output row m = lane & 15 and four consecutive columns n = 4 (lane >> 4) .. +3 of the 16 x 16 block
+    return f"v_mfma_f32_16x16x32_bf16 {acc(c, i, j)}, {fb(h, j)}, {fa(h, i)}, {cc}"
+
+
+def frag_reads(c, h, stage):
+    """ds_reads of k-half h of the K tile in `stage` into fragment set h: the weight fragments first (all of them are
+    needed by the first NBJ MFMAs of the phase that uses them), then the activation fragments in the order of use."""
+    r = []
+    for j in range(c.nbj):
+        r.append(f"ds_read_b128 {fb(h, j)}, %[raB{h}] offset:{stage * IMG + j * 2048}")
+    for i in range(8):
+        r.append(f"ds_read_b128 {fa(h, i)}, %[raA{h}] offset:{stage * IMG + i * 2048}")
+    return r
+
+
+def dma_ops(c, stage):
+    """(m0 setup, LDS-DMA) pairs of one K tile into `stage`."""
+    ops = []
+    for q in range(8):
+        ops.append((f"s_add_u32 m0, %[m0a], {stage * IMG + q * 1024}",
+                    f"buffer_load_dwordx4 %[voffA{q}], s[36:39], 0 offen lds"))
+    for q in range(c.npb):
+        ops.append((f"s_add_u32 m0, %[m0b], {stage * IMG + q * 1024}",
+                    f"buffer_load_dwordx4 %[voffB{q}], s[40:43], 0 offen lds"))
+    return ops
+
+
+ADVANCE = ["s_add_u32 s36, s36, 128", "s_addc_u32 s37, s37, 0", "s_sub_u32 s38, s38, 128",
+           "s_add_u32 s40, s40, 128", "s_addc_u32 s41, s41, 0", "s_sub_u32 s42, s42, 128"]
+
+
+def ktile(c, stage, first, sched):
+    """One K tile: 2 * nm MFMAs with the side instructions placed in the gaps after them (gap g = after MFMA g)."""
+    nm = c.nm
+    side = [[] for _ in range(2 * nm)]
+    # phase 1: k-half 1 of this K tile -> set 1
+    g = sched["read1_start"]
+    for ins in frag_reads(c, 1, stage):
+        side[g].append(ins)
+        g += sched["read_step"]
+    b1 = sched["b1_gap"]
+    assert g - sched["read_step"] < b1, "reads must be issued before B1"
+    side[b1].append("s_waitcnt lgkmcnt(0)")
+    side[b1].append("s_barrier")
+    # LDS-DMA of K tile t+2 into this stage, from B1 on: piece n in gap g, the next piece's M0 one gap later (an MFMA
+    # between a piece's issue and the M0 write behind it, and at least one between that write and its use)
+    g = b1 + 2
+    ops = dma_ops(c, stage)
+    side[b1 + 1].append(ops[0][0])
+    assert sched["dma_step"] >= 2
+    for n, (_, ld) in enumerate(ops):
+        side[g].append(ld)
+        if n + 1 < len(ops):
+            side[g + 1].append(ops[n + 1][0])
+        g += sched["dma_step"]
+    last_dma = g - sched["dma_step"]
+    side[last_dma + 1] += ADVANCE[0:3]       # (s_add / s_addc adjacent: nothing between them writes SCC)
+    side[last_dma + 2] += ADVANCE[3:6]
+    b2 = nm + sched["b2_gap"]
+    assert last_dma + 4 <= b2, (last_dma, b2)
+    side[b2].append(f"s_waitcnt vmcnt({c.ndma})")
+    side[b2].append("s_barrier")
+    # k-half 0 of K tile t+1 from the other stage -> set 0
+    g = b2 + 1
+    for ins in frag_reads(c, 0, stage ^ 1):
+        side[g].append(ins)
+        g += sched["read_step"]
+    assert g - sched["read_step"] <= 2 * nm - 2, (g, 2 * nm)
+    side[2 * nm - 2].append("s_waitcnt lgkmcnt(0)")
+    out = []
+    n = 0
+    for h in range(2):
+        for i in range(8):
+            for j in range(c.nbj):
+                out.append(mfma(c, h, i, j, first and h == 0))
+                out.extend(side[n])
+                n += 1
+    return out
+
+
+SWITCH = ["s_cmp_eq_u32 %[rem], 1",          # the last pair of K tiles prefetches the NEXT output tile's first two
+          "s_cselect_b32 s36, %[nal], s36", "s_cselect_b32 s37, %[nah], s37", "s_cselect_b32 s38, %[nan], s38",
+          "s_cselect_b32 s40, %[nbl], s40", "s_cselect_b32 s41, %[nbh], s41", "s_cselect_b32 s42, %[nbn], s42"]
+
+
+def tile_asm(c, sched):
+    t = []
+    t += frag_reads(c, 0, 0)                 # K tile 0 landed and was waited for by the previous block / the prologue
+    t += SWITCH
+    t.append("s_waitcnt lgkmcnt(0)")
+    t += ktile(c, 0, True, sched)
+    t += ktile(c, 1, False, sched)
+    t += ["s_sub_u32 %[rem], %[rem], 1", "s_cmp_eq_u32 %[rem], 0", "s_cbranch_scc1 L_a4_end_%="]
+    t.append("L_a4_loop_%=:")
+    t += SWITCH
+    t += ktile(c, 0, False, sched)
+    t += ktile(c, 1, False, sched)
+    t += ["s_sub_u32 %[rem], %[rem], 1", "s_cmp_lg_u32 %[rem], 0", "s_cbranch_scc1 L_a4_loop_%="]
+    t.append("L_a4_end_%=:")
+    t += ["s_nop 7", "s_nop 7"]              # MFMA results -> the compiler's v_accvgpr_read (it cannot see into this block)
+    return t
+
+
+def prologue_asm(c):
+    """First tile of a workgroup: K tiles 0 and 1 into stages 0 and 1, cursor left at K tile 2."""
+    t = []
+    for stage in range(2):
+        for m0, ld in dma_ops(c, stage):
+            t += [m0, "s_nop 0", ld]
+        t += ADVANCE
+    t += [f"s_waitcnt vmcnt({c.ndma})", "s_barrier"]
+    return t
+
+
+def emit(name, lines):
+    body = "\n".join('  "' + ln + '\\n"' for ln in lines)
+    return f"#define {name} \\\n" + body.replace("\n", " \\\n") + "\n"
+
+
+SCHED = {
+    8: {"read1_start": 1, "read_step": 1, "b1_gap": 24, "dma_step": 3, "b2_gap": 30},
+    6: {"read1_start": 1, "read_step": 1, "b1_gap": 20, "dma_step": 3, "b2_gap": 18},
+}
+
+
+def main():
+    parts = ["// GENERATED by tools/gen_gemm_a4.py - do not edit; the schedule is described there and in DESIGN.md 4.3.\n"
+             "// Operands: %[voffA0..7] %[voffB0..] per-lane source offsets; %[raA0/1] %[raB0/1] fragment read addresses of\n"
+             "// k-half 0 / 1; %[m0a] %[m0b] LDS destinations of this wave's first piece; %[rem] K-tile pairs left;\n"
+             "// %[nal/nah/nan/nbl/nbh/nbn] the next output tile's buffer words; s[36:39] / s[40:43] the operand cursors.\n"]
+    for nbj in (8, 6):
+        c = Cfg(nbj)
+        parts.append(emit(f"STONK_A4_PROLOGUE_{c.tag}", prologue_asm(c)))
+        parts.append(emit(f"STONK_A4_TILE_{c.tag}", tile_asm(c, SCHED[nbj])))
+    text = "\n".join(parts)
+    if len(sys.argv) > 1 and sys.argv[1] == "--check":
+        ok = open(OUT).read() == text
+        print("gemm_a4_loop.inc is", "up to date" if ok else "STALE")
+        sys.exit(0 if ok else 1)
+    with open(OUT, "w") as f:
+        f.write(text)
+    print("wrote", os.path.normpath(OUT), len(text), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,7 @@
 // bf16 MFMA GEMM, 256 x (256 | 192) x 64 tiles, FOUR waves per workgroup (one per SIMD, 128 x 128 | 96 wave tiles),
 // v_mfma_f32_16x16x32_bf16, operands by LDS-DMA (buffer_load ... lds), and a K loop whose instruction stream is
 // WRITTEN OUT: tools/gen_gemm_a4.py generates gemm_a4_loop.inc, one inline-assembly block per output tile.
-// Same contract as gemm_bf16.hip (C = epilogue(alpha * A[M,K] . B[N,K]^T)), bf16 output, no K split.
+// Same contract as gemm_bf16.hip (C = epilogue(A[M,K] . B[N,K]^T)), bf16 output, alpha = 1, no K split.
 //
 // Why a fourth NT kernel: gemm_w4.hip has this geometry in compiled C++ and keeps the matrix pipe
 // 54-64 % busy - with one wave per SIMD every instruction that is not in an MFMA's shadow delays the next MFMA, and the
@@ -18,7 +18,10 @@
 //    row, 4 consecutive columns per block) into 8 consecutive columns per lane, i.e. 16-byte stores and 16-byte side
 //    operand loads (residual, saved GELU') at the same addresses, requested a row block ahead.
 #include "gemm_common.h"
-#include "gemm_a4_loop.inc"
+#ifndef STONK_A4_LOOP_INC
+#define STONK_A4_LOOP_INC "gemm_a4_loop.inc"   // (tools/a4_sweep.py builds schedule variants against other files)
+#endif
+#include STONK_A4_LOOP_INC
 
 using namespace stonk_gemm;
 
@@ -34,6 +37,58 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 struct Work {
   int m0, n0;
 };
+
+// Exact (erf) GELU and its derivative on PAIRS of values: gelu(x) = x Phi(x), gelu'(x) = Phi(x) + x phi(x), with
+// erfc(|x| / sqrt 2) by Abramowitz & Stegun 7.1.26 as in common.h (|error| <= 1.5e-7) - the same formula, arranged so that
+// everything but the reciprocal, the exponential and the sign select is packed fp32 arithmetic (v_pk_fma_f32 /
+// v_pk_mul_f32: two values per issue slot): ~25 issue slots per pair where the scalar form takes ~23 per VALUE. The FFN-up
+// epilogue evaluates this on every output element and was as long as its K loop.
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+// v[8] -> gelu(v) in place; WITH_GRAD: u[8] = gelu'(v). The four pairs advance stage by stage (a dependent packed
+// instruction right behind its producer costs a wait state; four independent ones between them cost none).
+template <bool WITH_GRAD>
+__device__ __forceinline__ void gelu8(float (&v)[8], float (&u)[8]) {
+  const f32x2_ c1 = {1.061405429f, 1.061405429f}, c2 = {-1.453152027f, -1.453152027f}, c3 = {1.421413741f, 1.421413741f},
+               c4 = {-0.284496736f, -0.284496736f}, c5 = {0.254829592f, 0.254829592f}, half = {0.5f, 0.5f};
+  f32x2_ x[4], t[4], pl[4], a[4], e[4], h[4], cdf[4];
+#define STONK_A4_STAGE(...)                                                                                    \
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) { __VA_ARGS__; }                                                 \
+  __builtin_amdgcn_sched_barrier(0);   /* keeps the stages apart: the scheduler would re-serialise the pairs */
+  STONK_A4_STAGE(x[k] = ((f32x2_){v[2 * k], v[2 * k + 1]});
+                 t[k] = ((f32x2_){fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x[k][0]), 1.0f),
+                                  fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x[k][1]), 1.0f)});
+                 a[k] = x[k] * (f32x2_){-0.72134752044448170368f, -0.72134752044448170368f})   // -x^2 / 2 in the exp2 domain ...
+  STONK_A4_STAGE(t[k] = ((f32x2_){__builtin_amdgcn_rcpf(t[k][0]), __builtin_amdgcn_rcpf(t[k][1])}); a[k] = a[k] * x[k])
+  STONK_A4_STAGE(e[k] = ((f32x2_){__builtin_amdgcn_exp2f(a[k][0]), __builtin_amdgcn_exp2f(a[k][1])});   // exp(-x^2 / 2)
+                 pl[k] = __builtin_elementwise_fma(c1, t[k], c2))
+  STONK_A4_STAGE(pl[k] = __builtin_elementwise_fma(pl[k], t[k], c3))
+  STONK_A4_STAGE(pl[k] = __builtin_elementwise_fma(pl[k], t[k], c4))
+  STONK_A4_STAGE(pl[k] = __builtin_elementwise_fma(pl[k], t[k], c5))
+  STONK_A4_STAGE(pl[k] = pl[k] * t[k])
+  STONK_A4_STAGE(pl[k] = pl[k] * e[k])                                       // erfc(|x| / sqrt 2) = 2 Phi(-|x|)
+  STONK_A4_STAGE(h[k] = __builtin_elementwise_fma(pl[k], -half, half))       // 1/2 - Phi(-|x|) >= 0
+  // Phi(x) = 1/2 + sign(x) (1/2 - Phi(-|x|)): a v_bfi per value - a compare + select would go through an SGPR pair, two
+  // wait states each
+  STONK_A4_STAGE(cdf[k] = ((f32x2_){__builtin_copysignf(h[k][0], x[k][0]), __builtin_copysignf(h[k][1], x[k][1])}) + half)
+  if (WITH_GRAD) {
+    STONK_A4_STAGE(a[k] = x[k] * (f32x2_){0.39894228040143267794f, 0.39894228040143267794f})
+    STONK_A4_STAGE(const f32x2_ dg = __builtin_elementwise_fma(a[k], e[k], cdf[k]); u[2 * k] = dg[0]; u[2 * k + 1] = dg[1])
+  }
+  STONK_A4_STAGE(const f32x2_ g = x[k] * cdf[k]; v[2 * k] = g[0]; v[2 * k + 1] = g[1])
+#undef STONK_A4_STAGE
+}
+
+// eight fp32 -> eight bf16 by four v_cvt_pk_bf16_f32 (element-wise casts into a vector cost a conversion AND a v_perm each)
+__device__ __forceinline__ bf16x8 pack8(const float* e) {
+  typedef bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  union {
+    bf16x8 v;
+    bf16x2_ h[4];
+  } u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) u.h[j] = __builtin_convertvector((f32x2_){e[2 * j], e[2 * j + 1]}, bf16x2_);
+  return u.v;
+}
 
 template <int EPI, int BN_>
 __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
@@ -95,7 +150,11 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
   int voffA[8], voffB[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
+#ifdef STONK_A4_LINEAR_SRC   // timing experiment (tools/a4_sweep.py): unswizzled source, garbage results
+    const int c = (lane & 7) << 4;
+#else
     const int c = (((lane & 7) ^ (l8 >> 1) ^ (4 * (q & 1))) << 4);
+#endif
     voffA[q] = (wave * 64 + 8 * q + l8) * lda2 + c;
     voffB[q] = (wave * BROWS_W + 8 * (q < NPB ? q : 0) + l8) * ldb2 + c;
   }
@@ -225,24 +284,46 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
 #pragma unroll
       for (int jp = 0; jp < NJP; ++jp) cur[jp] = sd[jp];
       if (i + 1 < 8) side_request(i + 1);   // flies while this row block is processed
+      // Accumulator blocks (i, 2 jp) = x and (i, 2 jp + 1) = y of every pair jp. v_permlane16_swap exchanges x's odd
+      // rows of 16 lanes with y's even rows: afterwards (x, y) of a lane are columns 0-3 / 4-7 of its 8 consecutive output
+      // columns. One block per row block (inline assembly: this toolchain's __builtin_amdgcn_permlane16_swap returns its
+      // FIRST result twice; the no-ops stand in for the VALU <-> permlane wait states the compiler would have placed).
+      float xs[NJP][4], ys[NJP][4];
 #pragma unroll
       for (int jp = 0; jp < NJP; ++jp) {
-        const int bx = NBJ * i + 2 * jp, by = bx + 1;   // accumulator blocks (i, 2 jp) and (i, 2 jp + 1)
-        // rows of 16 lanes: x's odd rows <-> y's even rows. Afterwards (x, y) of a lane are columns 0-3 / 4-7 of its 8
-        // consecutive output columns. (Inline assembly: this toolchain's __builtin_amdgcn_permlane16_swap returns its
-        // FIRST result twice. The no-ops stand in for the VALU <-> permlane wait states the compiler would have placed.)
-        float x0 = acc[bx >> 2][4 * (bx & 3) + 0], x1 = acc[bx >> 2][4 * (bx & 3) + 1], x2 = acc[bx >> 2][4 * (bx & 3) + 2],
-              x3 = acc[bx >> 2][4 * (bx & 3) + 3];
-        float y0 = acc[by >> 2][4 * (by & 3) + 0], y1 = acc[by >> 2][4 * (by & 3) + 1], y2 = acc[by >> 2][4 * (by & 3) + 2],
-              y3 = acc[by >> 2][4 * (by & 3) + 3];
-        asm volatile("s_nop 1\n"
-                     "v_permlane16_swap_b32 %0, %4\n"
-                     "v_permlane16_swap_b32 %1, %5\n"
-                     "v_permlane16_swap_b32 %2, %6\n"
-                     "v_permlane16_swap_b32 %3, %7\n"
-                     "s_nop 1"
-                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
-        float v[8] = {x0 * p.alpha, x1 * p.alpha, x2 * p.alpha, x3 * p.alpha, y0 * p.alpha, y1 * p.alpha, y2 * p.alpha, y3 * p.alpha};
+        const int bx = NBJ * i + 2 * jp, by = bx + 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xs[jp][e] = acc[bx >> 2][4 * (bx & 3) + e];
+          ys[jp][e] = acc[by >> 2][4 * (by & 3) + e];
+        }
+      }
+#define STONK_A4_SWAP4(a, b) \
+  "v_permlane16_swap_b32 %" #a ", %" #b "\n"
+      if (NJP == 4) {
+        asm volatile("s_nop 1\n" STONK_A4_SWAP4(0, 16) STONK_A4_SWAP4(1, 17) STONK_A4_SWAP4(2, 18) STONK_A4_SWAP4(3, 19)
+                     STONK_A4_SWAP4(4, 20) STONK_A4_SWAP4(5, 21) STONK_A4_SWAP4(6, 22) STONK_A4_SWAP4(7, 23)
+                     STONK_A4_SWAP4(8, 24) STONK_A4_SWAP4(9, 25) STONK_A4_SWAP4(10, 26) STONK_A4_SWAP4(11, 27)
+                     STONK_A4_SWAP4(12, 28) STONK_A4_SWAP4(13, 29) STONK_A4_SWAP4(14, 30) STONK_A4_SWAP4(15, 31) "s_nop 1"
+                     : "+v"(xs[0][0]), "+v"(xs[0][1]), "+v"(xs[0][2]), "+v"(xs[0][3]), "+v"(xs[1][0]), "+v"(xs[1][1]),
+                       "+v"(xs[1][2]), "+v"(xs[1][3]), "+v"(xs[2][0]), "+v"(xs[2][1]), "+v"(xs[2][2]), "+v"(xs[2][3]),
+                       "+v"(xs[NJP - 1][0]), "+v"(xs[NJP - 1][1]), "+v"(xs[NJP - 1][2]), "+v"(xs[NJP - 1][3]),
+                       "+v"(ys[0][0]), "+v"(ys[0][1]), "+v"(ys[0][2]), "+v"(ys[0][3]), "+v"(ys[1][0]), "+v"(ys[1][1]),
+                       "+v"(ys[1][2]), "+v"(ys[1][3]), "+v"(ys[2][0]), "+v"(ys[2][1]), "+v"(ys[2][2]), "+v"(ys[2][3]),
+                       "+v"(ys[NJP - 1][0]), "+v"(ys[NJP - 1][1]), "+v"(ys[NJP - 1][2]), "+v"(ys[NJP - 1][3]));
+      } else {
+        asm volatile("s_nop 1\n" STONK_A4_SWAP4(0, 12) STONK_A4_SWAP4(1, 13) STONK_A4_SWAP4(2, 14) STONK_A4_SWAP4(3, 15)
+                     STONK_A4_SWAP4(4, 16) STONK_A4_SWAP4(5, 17) STONK_A4_SWAP4(6, 18) STONK_A4_SWAP4(7, 19)
+                     STONK_A4_SWAP4(8, 20) STONK_A4_SWAP4(9, 21) STONK_A4_SWAP4(10, 22) STONK_A4_SWAP4(11, 23) "s_nop 1"
+                     : "+v"(xs[0][0]), "+v"(xs[0][1]), "+v"(xs[0][2]), "+v"(xs[0][3]), "+v"(xs[1][0]), "+v"(xs[1][1]),
+                       "+v"(xs[1][2]), "+v"(xs[1][3]), "+v"(xs[2][0]), "+v"(xs[2][1]), "+v"(xs[2][2]), "+v"(xs[2][3]),
+                       "+v"(ys[0][0]), "+v"(ys[0][1]), "+v"(ys[0][2]), "+v"(ys[0][3]), "+v"(ys[1][0]), "+v"(ys[1][1]),
+                       "+v"(ys[1][2]), "+v"(ys[1][3]), "+v"(ys[2][0]), "+v"(ys[2][1]), "+v"(ys[2][2]), "+v"(ys[2][3]));
+      }
+#undef STONK_A4_SWAP4
+#pragma unroll
+      for (int jp = 0; jp < NJP; ++jp) {
+        float v[8] = {xs[jp][0], xs[jp][1], xs[jp][2], xs[jp][3], ys[jp][0], ys[jp][1], ys[jp][2], ys[jp][3]};
         const int n = wn0 + 32 * jp;
         const int oob = n < N ? 0 : 0x40000000;   // columns past N: pushed out of the buffers' range
         if (flags & STONK_EPI_BIAS) {
@@ -252,20 +333,24 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
             v[4 + e] += bq[jp][1][e];
           }
         }
-        if (flags & STONK_EPI_SAVE_PREACT) {
-          bf16x8 u;
+        int rest = flags & ~STONK_EPI_BIAS;
+        if (flags & STONK_EPI_GELU) {   // (with or without the saved pre-activation / saved GELU')
+          constexpr bool GRAD = (EPI & STONK_EPI_SAVE_PREACT) && (EPI & STONK_EPI_AUX_GRAD);
+          float u[8];
+          if (!GRAD) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) u[e] = (bf16)gelu_saved(v[e], (flags & STONK_EPI_AUX_GRAD) != 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, u), rX, m * ldx_b + n * 2 + oob, 0, 0);
+            for (int e = 0; e < 8; ++e) u[e] = v[e];   // (the plain form saves the pre-activation itself)
+          }
+          gelu8<GRAD>(v, u);
+          if (flags & STONK_EPI_SAVE_PREACT)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pack8(u)), rX, m * ldx_b + n * 2 + oob, 0, 0);
+          rest &= ~(STONK_EPI_GELU | STONK_EPI_SAVE_PREACT);
         }
         SideOps so;
         so.aux = so.res = cur[jp];
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        epilogue8_pre(v, p, flags & ~(STONK_EPI_BIAS | STONK_EPI_SAVE_PREACT), m, n, z4, z4, so);
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rC, m * ldc_b + n * 2 + oob, 0, 0);
+        epilogue8_pre(v, p, rest & ~STONK_EPI_SAVE_PREACT, m, n, z4, z4, so);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pack8(v)), rC, m * ldc_b + n * 2 + oob, 0, 0);
       }
     }
     if (!more) break;
@@ -291,7 +376,7 @@ int launch_a4(const GemmArgs& a, int grid, hipStream_t st) {
 
 }  // namespace
 
-// Launcher used by stonk_gemm_nt_bf16 (gemm_bf16.hip). Requires bf16 output, split_k == 1, K % 128 == 0, ld % 64 == 0,
+// Launcher used by stonk_gemm_nt_bf16 (gemm_bf16.hip). Requires bf16 output, alpha == 1, split_k == 1, K % 128 == 0, ld % 64 == 0,
 // 32-bit operand extents, 16-byte aligned side operands. tile_n: 0 = choose, 256, 192. items_per_wg as gemm_w4.hip.
 // Returns STONK_ESHAPE for an epilogue this kernel has no instance of (the caller then takes another kernel).
 int stonk_gemm_a4_launch(const GemmArgs& a, int tile_n, int items_per_wg, hipStream_t st) {

@@ -378,10 +378,18 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
         : (w4_ok && M >= 1024 && N % 192 == 0 && out_mode == STONK_EPI_OUT_BF16 && (flags & 0x1FC) == 0) ? STONK_GEMM_WAVE4
                                                                              : STONK_GEMM_TILE128;
   // the written-out four-wave kernel (gemm_a4.hip): bf16 output, no K split, no device-side K, one side operand at most
-  const bool a4_ok = w4_ok && out_mode == STONK_EPI_OUT_BF16 && split_k == 1 && (K / BK) >= 2;
+  const bool a4_ok = w4_ok && out_mode == STONK_EPI_OUT_BF16 && split_k == 1 && (K / BK) >= 2 && alpha == 1.0f;
   if (k == STONK_GEMM_ASM4 || k == STONK_GEMM_ASM4_192) {
     STONK_CHECK_ARG(a4_ok, STONK_ESHAPE);
     return stonk_gemm_a4_launch(a, k == STONK_GEMM_ASM4 ? 256 : 192, 0, st);
+  }
+  // AUTO (and DISPATCHED): every bf16-output launch of at least a thousand rows whose epilogue the written-out kernel has an
+  // instance of goes there (round 4, tools/a4_probe.py at 26 432 rows, alone, us: QKV 89 against 106 on the compiled
+  // four-wave kernel, attention-output 41 / 49, FFN-up 166 -> see profiles/ / 186, FFN-down 107 / 124, dgrad through GELU'
+  // 152 / 157, dgrad + residual 105 / 119 and 82 / 92, plain 768 x 768 36 / 39); it picks its tile width itself
+  if ((kernel == STONK_GEMM_AUTO || dispatched) && a4_ok && M >= 1024) {
+    const int rc = stonk_gemm_a4_launch(a, 0, !dispatched ? 0 : (kernel == STONK_GEMM_DISPATCHED2 ? 2 : 1), st);
+    if (rc != STONK_ESHAPE) return rc;   // (an epilogue it has no instance of: the older kernels below)
   }
   if (k == STONK_GEMM_WAVE4 || k == STONK_GEMM_WAVE4_192) {
     STONK_CHECK_ARG(w4_ok, STONK_ESHAPE);

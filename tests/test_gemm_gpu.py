@@ -387,3 +387,81 @@ def test_192_wide_tiles_need_n_divisible_by_192(hip):
     A, B = _rand((512, 256), 0.5, 61), _rand((256, 256), 0.05, 62)
     with pytest.raises(hip.StonkHipError, match="-2"):
         _gemm(hip, A, B, kernel=WAVE4_192)
+
+
+ASM4, ASM4_192 = 7, 8   # STONK_GEMM_ASM4 / _ASM4_192: the four-wave kernel with the written-out K loop (gemm_a4.hip)
+
+
+@pytest.mark.parametrize("kernel", [ASM4, ASM4_192])
+@pytest.mark.parametrize("M,N,K", [(256, 768, 128), (1000, 768, 768), (2050, 1536, 3072), (26408, 768, 768), (4096, 2304, 768),
+                                   (16384, 768, 2304)])
+def test_written_out_four_wave_kernel(hip, kernel, M, N, K):
+    """STONK_GEMM_ASM4 / _ASM4_192 (what AUTO takes for the bf16 launches of the step since round 4): plain product with a
+    ragged last row tile and several tiles per workgroup, bit-identical repeats (a misplaced wait of the hand-placed LDS-DMA
+    pipeline would show as rare differing tiles), every epilogue instance against torch fp32 on the same bf16 inputs, the
+    same dropout mask as the 128x128 kernel, a device-side row count; what it has no instance of is refused."""
+    if kernel == ASM4_192 and N % 192:
+        A, B = _rand((M, K), 0.5, 71), _rand((N, K), 0.05, 72)
+        with pytest.raises(hip.StonkHipError, match="-2"):
+            _gemm(hip, A, B, kernel=kernel)
+        return
+    A, B = _rand((M, K), 0.5, 71), _rand((N, K), 0.05, 72)
+    ref = A.float() @ B.float().t()
+    out = _gemm(hip, A, B, kernel=kernel)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
+    for _ in range(10):
+        assert torch.equal(_gemm(hip, A, B, kernel=kernel), out)
+    bias = torch.randn(N, device="cuda")
+    resid = _rand((M, N), 1.0, 73)
+    out = _gemm(hip, A, B, flags=hip.EPI_BIAS, bias=bias, kernel=kernel)
+    torch.testing.assert_close(out.float(), ref + bias, rtol=2e-2, atol=2e-2)
+    out = _gemm(hip, A, B, flags=hip.EPI_RESID, resid=resid, kernel=kernel)
+    torch.testing.assert_close(out.float(), ref + resid.float(), rtol=2e-2, atol=3e-2)
+    out = _gemm(hip, A, B, flags=hip.EPI_BIAS | hip.EPI_RESID, bias=bias, resid=resid, kernel=kernel)
+    torch.testing.assert_close(out.float(), ref + bias + resid.float(), rtol=2e-2, atol=3e-2)
+    fl = hip.EPI_BIAS | hip.EPI_RESID | hip.EPI_DROPOUT
+    da = _gemm(hip, A, B, flags=fl, bias=bias, resid=resid, drop_p=0.1, seed=9, kernel=kernel).float() - resid.float()
+    d128 = _gemm(hip, A, B, flags=fl, bias=bias, resid=resid, drop_p=0.1, seed=9, kernel=T128).float() - resid.float()
+    pre = ref + bias
+    kept = (da.abs() > 1e-3) | (pre.abs() < 1e-2)
+    assert abs(1.0 - kept.float().mean().item() - 0.1) < 0.02
+    assert (da.abs() > 1e-3).eq(d128.abs() > 1e-3).float().mean().item() > 0.999      # one mask per (seed, row, column)
+    torch.testing.assert_close(torch.where(kept, da, torch.zeros_like(da)),
+                               torch.where(kept, pre / 0.9, torch.zeros_like(pre)), rtol=3e-2, atol=6e-2)
+    cut = max(1, M - 37)
+    m_dev = torch.tensor([cut], device="cuda", dtype=torch.int32)
+    C = torch.full((M, N), -7.0, device="cuda", dtype=torch.bfloat16)
+    _gemm(hip, A, B, C=C, m_dev=m_dev, kernel=kernel)
+    torch.testing.assert_close(C[:cut].float(), ref[:cut], rtol=2e-2, atol=2e-2)
+    assert (C[cut:] == -7.0).all()
+    if kernel == ASM4:   # the GELU family (256-wide tiles only)
+        gelu = torch.nn.functional.gelu
+        out = _gemm(hip, A, B, flags=hip.EPI_BIAS | hip.EPI_GELU, bias=bias, kernel=kernel)
+        torch.testing.assert_close(out.float(), gelu(pre), rtol=1e-2, atol=2e-2)
+        for ag in (0, hip.EPI_AUX_GRAD):
+            aux = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+            out = _gemm(hip, A, B, flags=hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_SAVE_PREACT | ag, bias=bias, aux=aux, kernel=kernel)
+            torch.testing.assert_close(out.float(), gelu(pre), rtol=1e-2, atol=2e-2)
+            if ag:
+                pf = pre.clone().requires_grad_(True)
+                (gpre,) = torch.autograd.grad(gelu(pf).sum(), pf)
+                torch.testing.assert_close(aux.float(), gpre, rtol=1e-2, atol=1e-2)
+            else:
+                torch.testing.assert_close(aux.float(), pre, rtol=1e-2, atol=2e-2)
+        u = _rand((M, N), 1.0, 74)
+        uf = u.float().requires_grad_(True)
+        (gp,) = torch.autograd.grad(gelu(uf).sum(), uf)
+        out = _gemm(hip, A, B, flags=hip.EPI_GELU_BWD, aux=u, kernel=kernel)
+        torch.testing.assert_close(out.float(), ref * gp, rtol=1e-2, atol=3e-2)
+        out = _gemm(hip, A, B, flags=hip.EPI_GELU_BWD | hip.EPI_AUX_GRAD, aux=u, kernel=kernel)
+        torch.testing.assert_close(out.float(), ref * u.float(), rtol=1e-2, atol=3e-2)
+    else:
+        with pytest.raises(hip.StonkHipError, match="-2"):
+            _gemm(hip, A, B, flags=hip.EPI_BIAS | hip.EPI_GELU, bias=bias, kernel=kernel)
+    with pytest.raises(hip.StonkHipError, match="-2"):   # fp32 output, a scaled product, an odd number of K tiles
+        _gemm(hip, A, B, torch.float32, flags=hip.EPI_OUT_F32, kernel=kernel)
+    with pytest.raises(hip.StonkHipError, match="-2"):
+        _gemm(hip, A, B, alpha=0.5, kernel=kernel)
+    if K >= 192:
+        with pytest.raises(hip.StonkHipError, match="-2"):
+            _gemm(hip, A[:, :K - 64], B[:, :K - 64], kernel=kernel)

@@ -135,10 +135,12 @@ def timing(T):
         kw = dict(bias=bias if fl & hip.EPI_BIAS else None, resid=side if fl & hip.EPI_RESID else None,
                   aux=(side if fl & hip.EPI_GELU_BWD else aux) if fl & (hip.EPI_GELU_BWD | hip.EPI_SAVE_PREACT) else None,
                   drop_p=0.1 if fl & hip.EPI_DROPOUT else 0.0, seed=5)
-        arms = {"w4(auto)": lambda: gemm(A, B, flags=fl, kernel=hip.GEMM_AUTO, C=C, **kw),
+        arms = {"w4_256": lambda: gemm(A, B, flags=fl, kernel=hip.GEMM_WAVE4, C=C, **kw),
                 "a4_256": lambda: gemm(A, B, flags=fl, kernel=hip.GEMM_ASM4, C=C, **kw)}
         if N % 192 == 0 and fl in (0, hip.EPI_BIAS, hip.EPI_RESID, hip.EPI_BIAS | hip.EPI_RESID, hip.EPI_BIAS | hip.EPI_RESID | hip.EPI_DROPOUT):
+            arms["w4_192"] = lambda: gemm(A, B, flags=fl, kernel=hip.GEMM_WAVE4_192, C=C, **kw)
             arms["a4_192"] = lambda: gemm(A, B, flags=fl, kernel=hip.GEMM_ASM4_192, C=C, **kw)
+        arms["auto"] = lambda: gemm(A, B, flags=fl, kernel=hip.GEMM_AUTO, C=C, **kw)
         if fl == 0:
             arms["vendor"] = lambda: torch.matmul(A, B.t(), out=C)
         res = {k: [] for k in arms}

@@ -87,43 +87,66 @@ ADVANCE = ["s_add_u32 s36, s36, 128", "s_addc_u32 s37, s37, 0", "s_sub_u32 s38, 
 
 
 def ktile(c, stage, first, sched):
-    """One K tile: 2 * nm MFMAs with the side instructions placed in the gaps after them (gap g = after MFMA g)."""
+    """One K tile: 2 * nm MFMAs with the side instructions placed in the gaps after them (gap g = after MFMA g). A gap
+    carries at most ONE memory instruction (an LDS read or an LDS-DMA issue): `place` takes the first free gap at or
+    after the one asked for. `ablate` (timing experiments only, results are garbage): "dma" / "reads" leave those out."""
     nm = c.nm
+    ablate = sched.get("ablate", ())
     side = [[] for _ in range(2 * nm)]
+    busy = [False] * (2 * nm)
+
+    def place(g, ins):
+        while busy[g]:
+            g += 1
+        busy[g] = True
+        side[g].append(ins)
+        return g
+
     # phase 1: k-half 1 of this K tile -> set 1
     g = sched["read1_start"]
+    last_read = g
     for ins in frag_reads(c, 1, stage):
-        side[g].append(ins)
+        if "reads" not in ablate:
+            last_read = place(g, ins)
         g += sched["read_step"]
     b1 = sched["b1_gap"]
-    assert g - sched["read_step"] < b1, "reads must be issued before B1"
+    assert last_read < b1, "reads must be issued before B1"
     side[b1].append("s_waitcnt lgkmcnt(0)")
     side[b1].append("s_barrier")
-    # LDS-DMA of K tile t+2 into this stage, from B1 on: piece n in gap g, the next piece's M0 one gap later (an MFMA
-    # between a piece's issue and the M0 write behind it, and at least one between that write and its use)
+    # B2: K tile t+1 (issued one K tile earlier) has landed; behind it, k-half 0 of K tile t+1 from the other stage -> set 0
+    # (placed first: its gaps are fixed, the LDS-DMA issues then take the free gaps around them)
+    b2 = nm + sched["b2_gap"]
+    g = b2 + 1
+    step2 = sched.get("read2_step", sched["read_step"])
+    for ins in frag_reads(c, 0, stage ^ 1):
+        if "reads" not in ablate:
+            last_read = place(g, ins)
+        g += step2
+    assert last_read <= 2 * nm - 2, (last_read, 2 * nm)
+    side[2 * nm - 2].append("s_waitcnt lgkmcnt(0)")
+    # LDS-DMA of K tile t+2 into this stage, from B1 on: piece n in a gap of its own, the next piece's M0 one gap later (an
+    # MFMA between a piece's issue and the M0 write behind it, and at least one between that write and its use)
     g = b1 + 2
     ops = dma_ops(c, stage)
-    side[b1 + 1].append(ops[0][0])
     assert sched["dma_step"] >= 2
-    for n, (_, ld) in enumerate(ops):
-        side[g].append(ld)
-        if n + 1 < len(ops):
-            side[g + 1].append(ops[n + 1][0])
-        g += sched["dma_step"]
-    last_dma = g - sched["dma_step"]
+    m0_gap = b1 + 1
+    last_dma = b1
+    for n, (m0, ld) in enumerate(ops):
+        if "dma" in ablate:
+            break
+        side[m0_gap].append(m0)
+        at = place(max(g, m0_gap + 1), ld)
+        m0_gap = at + 1
+        last_dma = at
+        g = at + sched["dma_step"]
+    assert last_dma + 2 < 2 * nm, last_dma
     side[last_dma + 1] += ADVANCE[0:3]       # (s_add / s_addc adjacent: nothing between them writes SCC)
     side[last_dma + 2] += ADVANCE[3:6]
-    b2 = nm + sched["b2_gap"]
-    assert last_dma + 4 <= b2, (last_dma, b2)
-    side[b2].append(f"s_waitcnt vmcnt({c.ndma})")
-    side[b2].append("s_barrier")
-    # k-half 0 of K tile t+1 from the other stage -> set 0
-    g = b2 + 1
-    for ins in frag_reads(c, 0, stage ^ 1):
-        side[g].append(ins)
-        g += sched["read_step"]
-    assert g - sched["read_step"] <= 2 * nm - 2, (g, 2 * nm)
-    side[2 * nm - 2].append("s_waitcnt lgkmcnt(0)")
+    # the wait of B2 counts what THIS K tile has issued before it: all but those pieces must be done
+    issued = sum(1 for gg in range(b2) for ins in side[gg] if ins.startswith("buffer_load"))   # (gap b2 itself: wait first)
+    if "dma" not in ablate:
+        side[b2].insert(0, f"s_waitcnt vmcnt({issued})")
+    side[b2].insert(1 if "dma" not in ablate else 0, "s_barrier")
     out = []
     n = 0
     for h in range(2):
@@ -174,28 +197,42 @@ def emit(name, lines):
     return f"#define {name} \\\n" + body.replace("\n", " \\\n") + "\n"
 
 
+# Where the side instructions sit (gap = after that MFMA of the K tile). Chosen on MI355X by tools/a4_sweep.py (round 4,
+# profiles/r04_a4_sweep.md): an LDS-DMA issue is the expensive instruction of this loop (8192^3: 587 us with neither reads nor
+# DMA, 619 with the reads, 820 with the DMA one gap in three, 750 one gap in six) - so the pieces are spread as far apart
+# as the K tile allows; the reads cost little wherever they are; B1 as early as the k-half-1 reads allow.
 SCHED = {
-    8: {"read1_start": 1, "read_step": 1, "b1_gap": 24, "dma_step": 3, "b2_gap": 30},
-    6: {"read1_start": 1, "read_step": 1, "b1_gap": 20, "dma_step": 3, "b2_gap": 18},
+    8: {"read1_start": 1, "read_step": 1, "b1_gap": 20, "dma_step": 6, "b2_gap": 30},
+    6: {"read1_start": 1, "read_step": 1, "b1_gap": 18, "dma_step": 4, "b2_gap": 28},
 }
 
 
-def main():
+def generate(path, overrides=None):
+    """Writes the include file; `overrides` = {8: {...}, 6: {...}} replaces schedule entries (tools/a4_sweep.py)."""
     parts = ["// GENERATED by tools/gen_gemm_a4.py - do not edit; the schedule is described there and in DESIGN.md 4.3.\n"
              "// Operands: %[voffA0..7] %[voffB0..] per-lane source offsets; %[raA0/1] %[raB0/1] fragment read addresses of\n"
              "// k-half 0 / 1; %[m0a] %[m0b] LDS destinations of this wave's first piece; %[rem] K-tile pairs left;\n"
              "// %[nal/nah/nan/nbl/nbh/nbn] the next output tile's buffer words; s[36:39] / s[40:43] the operand cursors.\n"]
     for nbj in (8, 6):
         c = Cfg(nbj)
+        sched = dict(SCHED[nbj])
+        sched.update((overrides or {}).get(nbj, {}))
         parts.append(emit(f"STONK_A4_PROLOGUE_{c.tag}", prologue_asm(c)))
-        parts.append(emit(f"STONK_A4_TILE_{c.tag}", tile_asm(c, SCHED[nbj])))
+        parts.append(emit(f"STONK_A4_TILE_{c.tag}", tile_asm(c, sched)))
     text = "\n".join(parts)
+    if path is None:
+        return text
+    with open(path, "w") as f:
+        f.write(text)
+    return text
+
+
+def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--check":
-        ok = open(OUT).read() == text
+        ok = open(OUT).read() == generate(None)
         print("gemm_a4_loop.inc is", "up to date" if ok else "STALE")
         sys.exit(0 if ok else 1)
-    with open(OUT, "w") as f:
-        f.write(text)
+    text = generate(OUT)
     print("wrote", os.path.normpath(OUT), len(text), "bytes")
 
 

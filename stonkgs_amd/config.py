@@ -27,6 +27,10 @@ class STonKGsConfig:
     model_type: str = "bert"
     num_labels: int = 2                   # fine-tuning head only (ref:stonkgs_finetuning.py:247)
     problem_type: str = None              # None -> inferred from num_labels / label dtype, as the reference does
+    # The reference hands `self.bert(...).attentions` through (ref:stonkgs_model.py:256): None unless the HF config says
+    # output_attentions. Here the attention probabilities never exist in memory (flash-style kernels keep a row's
+    # running maximum and sum), so a config that asks for them is REFUSED rather than answered with None.
+    output_attentions: bool = False
 
     @property
     def half_length(self) -> int:  # ref:stonkgs_model.py:52
@@ -48,6 +52,10 @@ class STonKGsConfig:
             raise ValueError("only the exact erf GELU of BERT is implemented")
         if self.type_vocab_size != 2:
             raise ValueError("type_vocab_size must be 2")
+        if self.output_attentions:
+            raise NotImplementedError(
+                "output_attentions=True: the gfx950 attention kernels never materialise the [B, heads, S, S] probabilities "
+                "(online softmax), so `attentions` cannot be returned; run the reference's CPU path for attention maps")
 
     def update(self, d: dict) -> None:
         for k, v in d.items():

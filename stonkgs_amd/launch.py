@@ -12,6 +12,11 @@ The reference leaves this to whatever launches HF ``Trainer`` (ref:src/stonkgs/m
 * every rank's stdout / stderr goes to a FILE (no pipe that a dead reader can block, nothing lost on a timeout); rank 0's
   stderr is relayed while the job runs, its stdout (the one JSON line of bench.py) when it ends.
 
+* the ranks do not outlive the launcher: SIGTERM / SIGHUP / SIGINT to the launcher (an outer ``timeout``, a harness step
+  limit, a closed terminal) stop every rank's process group before it exits non-zero, and a launcher that is SIGKILLed -
+  which no handler sees - takes its ranks with it through PR_SET_PDEATHSIG (each rank asks the kernel for SIGKILL when
+  its parent dies).
+
 Nothing here touches a GPU: the parent may start ranks before or without initialising HIP, and never replaces itself.
 """
 from __future__ import annotations
@@ -68,22 +73,49 @@ def _signal_group(p: subprocess.Popen, sig: int) -> None:
         pass
 
 
+def _group_alive(p: subprocess.Popen) -> bool:
+    try:
+        os.killpg(p.pid, 0)
+        return True
+    except (ProcessLookupError, PermissionError):
+        return False
+
+
 def stop_ranks(procs: Sequence[subprocess.Popen], grace: float = 5.0) -> None:
-    """SIGTERM every rank's process group, wait `grace` seconds, SIGKILL what is left, reap everything."""
-    live = [p for p in procs if p.poll() is None]
-    for p in live:
+    """SIGTERM every rank's process group, wait `grace` seconds, SIGKILL what is left, reap everything. EVERY rank's group
+    is signalled, also that of a rank whose leader has exited: what it started (a data-loader worker, a helper that still
+    holds the GPU) is in that group, and a group id cannot be reused while the group has members."""
+    for p in procs:
         _signal_group(p, signal.SIGTERM)
     t_end = time.time() + grace
-    while time.time() < t_end and any(p.poll() is None for p in live):
+    while time.time() < t_end and any(p.poll() is None or _group_alive(p) for p in procs):
         time.sleep(0.05)
-    for p in live:
-        if p.poll() is None:
+    for p in procs:
+        if p.poll() is None or _group_alive(p):
             _signal_group(p, signal.SIGKILL)
     for p in procs:
         try:
             p.wait(timeout=10)
         except subprocess.TimeoutExpired:   # (unkillable: a process stuck in the driver; nothing more a parent can do)
             pass
+
+
+class _Stopped(BaseException):
+    """Raised by the launcher's signal handlers into `run_ranks`, whose `finally` stops the ranks."""
+
+    def __init__(self, signum: int):
+        super().__init__(signum)
+        self.signum = signum
+
+
+def _die_with_parent() -> None:
+    """preexec_fn of a rank: SIGKILL from the kernel when the launcher dies (prctl(PR_SET_PDEATHSIG) - Linux)."""
+    try:
+        import ctypes
+
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL)   # PR_SET_PDEATHSIG = 1
+    except Exception:
+        pass
 
 
 def run_ranks(world: int, argv: Sequence[str], timeout: float, env: Optional[Dict[str, str]] = None,
@@ -97,13 +129,24 @@ def run_ranks(world: int, argv: Sequence[str], timeout: float, env: Optional[Dic
     port = free_port()
     logdir = tempfile.mkdtemp(prefix="stonk_ranks_")
     files, procs = [], []
+    # SIGTERM / SIGHUP / SIGINT to the launcher become an exception here, so that the `finally` below runs (handlers can
+    # only be installed from the main thread; elsewhere the caller keeps that responsibility)
+    handled = {}
+    import threading
+
+    if threading.current_thread() is threading.main_thread():
+        def _raise(signum, _frame):
+            raise _Stopped(signum)
+
+        for sig in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
+            handled[sig] = signal.signal(sig, _raise)
     try:
         for r in range(world):
             fo = open(os.path.join(logdir, f"rank{r}.out"), "w+b")
             fe = open(os.path.join(logdir, f"rank{r}.err"), "w+b")
             files.append((fo, fe))
             procs.append(subprocess.Popen(list(argv), env=rank_env(r, world, port, env), stdout=fo, stderr=fe,
-                                          stdin=subprocess.DEVNULL, start_new_session=True))
+                                          stdin=subprocess.DEVNULL, start_new_session=True, preexec_fn=_die_with_parent))
         t_end = time.time() + timeout
         relayed = 0
         failed_at = None
@@ -135,8 +178,17 @@ def run_ranks(world: int, argv: Sequence[str], timeout: float, env: Optional[Dic
             sys.stdout.write(outs[0])
             sys.stdout.flush()
         return RankResult(rc, timed_out, outs, errs, codes)
+    except _Stopped as stop:
+        for sig in handled:                  # (a second signal while the ranks are being stopped must not interrupt that)
+            signal.signal(sig, signal.SIG_IGN)
+        stop_ranks(procs)
+        sys.stderr.write(f"[launch] signal {stop.signum}: {world} ranks stopped\n")
+        sys.stderr.flush()
+        raise SystemExit(128 + stop.signum)
     finally:
         stop_ranks(procs, grace=0.0)
+        for sig, old in handled.items():
+            signal.signal(sig, old)
         for fo, fe in files:
             fo.close()
             fe.close()

@@ -406,6 +406,8 @@ class STonKGsForPreTraining(nn.Module):
         dev = self._device
         if input_ids is None:
             raise ValueError("input_ids is required")
+        if getattr(cfg, "output_attentions", False):   # (set after construction: the constructor refuses it already)
+            cfg.validate_for_hip()
 
         def prep(t):
             if t is None:

@@ -421,8 +421,14 @@ class Trainer:
 
     # checkpoint / resume (ref:stonkgs_pretraining.py:185-186,196-223: save_steps, save_total_limit, resume)
     def save_checkpoint(self) -> str:
+        """Rank 0 writes. With a SHARDED optimizer this is a collective - every rank must call it (each holds 1/world of
+        Adam's state, gathered here into the flat layout a checkpoint carries whatever the sharding) - and `Trainer.train`
+        does; with replicated state the other ranks return at once and copy nothing."""
         self.model.engine.wait_params()
         d = os.path.join(self.args.output_dir, f"checkpoint-{self.global_step}")
+        sharded = bool(getattr(self.sync, "shard", False))
+        if self.rank != 0 and not sharded:
+            return d
         opt_state = self.optimizer.state_dict(self.sync)
         if self.rank != 0:
             return d
@@ -461,17 +467,34 @@ def get_last_checkpoint(folder: str) -> Optional[str]:
     return os.path.join(folder, max(c, key=lambda x: int(x.split("-")[1]))) if c else None
 
 
-def pretrain_stonkgs(model, train_dataset, batch_size: int = 8, lr: float = 1e-4, max_steps: int = 10000,
-                     gradient_accumulation_steps: int = 1, logging_steps: int = 100, training_dir: str = "pretraining",
-                     overwrite_output_dir: bool = False):
+def pretrain_stonkgs(model, train_dataset, batch_size: int = 8, deepspeed: bool = False, fp16: bool = True, lr: float = 1e-4,
+                     dataloader_num_workers: int = 2, gradient_accumulation_steps: int = 1, logging_steps: int = 100,
+                     max_steps: int = 10000, overwrite_output_dir: bool = False, save_limit: int = 5, save_steps: int = 5000,
+                     training_dir: str = "pretraining"):
     """ref:stonkgs_pretraining.py:103-230 without mlflow / hub: build args, resume if a checkpoint exists (raise if
-    the directory is non-empty without one, as the reference does :203-207), train, save."""
+    the directory is non-empty without one, as the reference does :203-207), train, save.
+
+    The reference's keyword arguments keep their names, defaults and meaning (`:103-120`); what they map to here:
+    `deepspeed` -> `TrainingArguments.shard_optimizer` (the reference's DeepSpeed configuration is ZeRO stage 2: optimizer
+    state and gradients partitioned over the ranks - the sharded optimizer of this build, no DeepSpeed involved);
+    `fp16` is accepted and has no effect: the step always computes in bf16 with fp32 master weights and fp32 accumulation,
+    which needs no loss scaling (BASELINE config 2; `fp16=False` would ask for an fp32 path this build does not have and
+    is refused); `save_limit` -> `save_total_limit`; `save_steps` as is; `dataloader_num_workers` is accepted and unused
+    (batches are assembled on the device or handed over as tensors: there is no worker pool to size). The model and the
+    dataset are passed in (the reference builds them from hub names / a pickled frame: out of scope)."""
+    if not fp16:
+        raise ValueError("fp16=False asks for a full-precision training step; this build computes in bf16 (fp32 master "
+                         "weights and accumulation) and has no fp32 path")
+    del dataloader_num_workers
     args = TrainingArguments(output_dir=training_dir, per_device_train_batch_size=batch_size, max_steps=max_steps,
                              learning_rate=lr, gradient_accumulation_steps=gradient_accumulation_steps,
-                             logging_steps=logging_steps)
-    last = get_last_checkpoint(training_dir)
-    if last is None and os.path.isdir(training_dir) and os.listdir(training_dir) and not overwrite_output_dir:
-        raise ValueError(f"Output directory ({training_dir}) already exists and is not empty.")
+                             logging_steps=logging_steps, save_steps=save_steps, save_total_limit=save_limit,
+                             shard_optimizer=bool(deepspeed))
+    last = None
+    if os.path.isdir(training_dir) and not overwrite_output_dir:
+        last = get_last_checkpoint(training_dir)
+        if last is None and os.listdir(training_dir):
+            raise ValueError(f"Output directory ({training_dir}) already exists and is not empty.")
     trainer = Trainer(model=model, args=args, train_dataset=train_dataset)
     result = trainer.train(resume_from_checkpoint=last)
     trainer.save_model()

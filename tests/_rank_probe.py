@@ -25,6 +25,15 @@ elif mode == "hang":
         child = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"])
         print(f"grandchild {child.pid}", flush=True)
     time.sleep(600)
+elif mode == "hang_pidfile":   # as "hang", reporting the pids through a file (the launcher's own output is not read)
+    pids = [os.getpid()]
+    if rank == 1:
+        import subprocess
+
+        pids.append(subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"]).pid)
+    with open(sys.argv[2], "a") as f:
+        f.write(" ".join(map(str, pids)) + "\n")
+    time.sleep(600)
 elif mode == "die":
     if rank == 0:
         sys.exit(7)

@@ -113,6 +113,61 @@ def test_launcher_stops_the_peers_of_a_dead_rank():
     assert time.time() - t0 < 30
 
 
+def _pids_gone(pids, wait=5.0):
+    import time
+
+    t_end = time.time() + wait
+    while True:
+        alive = []
+        for pid in pids:
+            try:
+                os.kill(pid, 0)
+                if open(f"/proc/{pid}/stat").read().split()[2] != "Z":
+                    alive.append(pid)
+            except (ProcessLookupError, FileNotFoundError):
+                pass
+        if not alive or time.time() > t_end:
+            return alive
+        time.sleep(0.1)
+
+
+@pytest.mark.parametrize("sig", ["TERM", "KILL"])
+def test_ranks_do_not_outlive_the_launcher(tmp_path, sig):
+    """An outer `timeout` / harness limit stops the LAUNCHER, not the ranks (each leads a session of its own): SIGTERM is
+    turned into a stop of every rank's group by the launcher's handler, SIGKILL - which nothing can handle - reaches the
+    ranks through PR_SET_PDEATHSIG. Either way no rank keeps running (and keeps its GPU)."""
+    import signal
+    import subprocess
+    import sys
+    import time
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    pidfile = tmp_path / "pids"
+    code = (f"import sys; sys.path.insert(0, {root!r})\n"
+            "from stonkgs_amd.launch import run_ranks\n"
+            f"run_ranks(2, [sys.executable, {os.path.join(here, '_rank_probe.py')!r}, 'hang_pidfile', {str(pidfile)!r}], timeout=300)\n")
+    launcher = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    t_end = time.time() + 60
+    while time.time() < t_end and not (pidfile.exists() and len(pidfile.read_text().split()) >= 3):
+        time.sleep(0.1)
+    pids = [int(x) for x in pidfile.read_text().split()]
+    assert len(pids) >= 3, "two ranks and rank 1's grandchild should have reported"
+    launcher.send_signal(signal.SIGTERM if sig == "TERM" else signal.SIGKILL)
+    rc = launcher.wait(timeout=30)
+    assert rc != 0
+    if sig == "TERM":
+        assert rc == 128 + signal.SIGTERM and b"ranks stopped" in launcher.stderr.read()
+        assert not _pids_gone(pids), "ranks (or the grandchild) survived a SIGTERMed launcher"
+    else:
+        assert not _pids_gone(pids[:2]), "ranks survived a SIGKILLed launcher"     # (the parent-death signal is per child)
+        for pid in pids[2:]:
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+
+
 # ---- optimizer sharding (TrainingArguments.shard_optimizer): reduce into the owned piece of every bucket, update it,
 # all-gather the parameters - world 2 over gloo
 def _shard_worker(rank, world, port, q):

@@ -141,6 +141,17 @@ def test_model_fails_loudly_without_gpu():
         STonKGsForPreTraining(STonKGsConfig())
 
 
+def test_output_attentions_is_refused_not_answered_with_none():
+    """ref:stonkgs_model.py:256 returns `outputs.attentions` (None unless the HF config asks for them). The gfx950 attention
+    never materialises the probabilities, so a config that asks is refused where the config meets the kernels - also when
+    it comes in as a dict / BertConfig-like object (the flag must not be dropped on the way)."""
+    cfg = STonKGsConfig.from_any({"output_attentions": True, "hidden_size": 768})
+    assert cfg.output_attentions is True
+    with pytest.raises(NotImplementedError, match="output_attentions"):
+        cfg.validate_for_hip()
+    STonKGsConfig().validate_for_hip()
+
+
 def test_embedding_helper_batching_is_host_only_logic():
     """Row collection / batching of stonkgs_for_embeddings (f2): DataFrame, list-of-dicts and dict-of-columns inputs,
     ragged last batch, optional columns, index selection - no GPU needed."""
@@ -204,6 +215,52 @@ def test_pretrain_refuses_a_non_empty_output_dir_without_checkpoint(tmp_path):
         (tmp_path / f"checkpoint-{n}").mkdir()
     (tmp_path / "checkpoint-final").mkdir()   # not a step directory
     assert get_last_checkpoint(str(tmp_path)).endswith("checkpoint-10")
+
+
+def test_pretrain_driver_takes_the_reference_keywords(tmp_path, monkeypatch):
+    """ref:stonkgs_pretraining.py:103-120: batch_size, deepspeed, fp16, lr, dataloader_num_workers,
+    gradient_accumulation_steps, logging_steps, max_steps, overwrite_output_dir, save_limit, save_steps, training_dir - same
+    names and defaults; `deepspeed=True` reaches the sharded optimizer, `save_steps` / `save_limit` the checkpoint cadence,
+    `fp16=False` (an fp32 step) is refused. Host logic only: the Trainer is replaced by a recorder."""
+    import inspect
+
+    from stonkgs_amd import stonkgs_pretraining as sp
+
+    sig = inspect.signature(sp.pretrain_stonkgs)
+    want = dict(batch_size=8, deepspeed=False, fp16=True, lr=1e-4, dataloader_num_workers=2, gradient_accumulation_steps=1,
+                logging_steps=100, max_steps=10000, overwrite_output_dir=False, save_limit=5, save_steps=5000)
+    for k, v in want.items():
+        assert sig.parameters[k].default == v, k
+    seen = {}
+
+    class Recorder:
+        def __init__(self, model, args, train_dataset):
+            seen["args"] = args
+
+        def train(self, resume_from_checkpoint=None):
+            seen["resume"] = resume_from_checkpoint
+            return {}
+
+        def save_model(self):
+            seen["saved"] = True
+
+    monkeypatch.setattr(sp, "Trainer", Recorder)
+    out = tmp_path / "run"
+    sp.pretrain_stonkgs(object(), [], batch_size=4, deepspeed=True, lr=3e-5, max_steps=77, save_steps=11, save_limit=2,
+                        logging_steps=5, gradient_accumulation_steps=3, training_dir=str(out))
+    a = seen["args"]
+    assert (a.shard_optimizer, a.save_steps, a.save_total_limit, a.max_steps, a.learning_rate, a.logging_steps,
+            a.per_device_train_batch_size, a.gradient_accumulation_steps) == (True, 11, 2, 77, 3e-5, 5, 4, 3)
+    assert seen["resume"] is None and seen["saved"]
+    with pytest.raises(ValueError, match="fp16=False"):
+        sp.pretrain_stonkgs(object(), [], fp16=False, training_dir=str(out))
+    # a non-empty directory: refused, unless overwrite_output_dir (which also ignores checkpoints, as the reference :197-201)
+    out.mkdir(exist_ok=True)
+    (out / "checkpoint-3").mkdir()
+    sp.pretrain_stonkgs(object(), [], training_dir=str(out))
+    assert seen["resume"].endswith("checkpoint-3")
+    sp.pretrain_stonkgs(object(), [], training_dir=str(out), overwrite_output_dir=True)
+    assert seen["resume"] is None
 
 
 def test_bench_contract_constants():

@@ -83,6 +83,54 @@ def test_real_depth_matches_reference_golden(hip):
     for k in meta["grad_keys"]:
         e = _rel(gv[k][_slice_of(meta["grad_slices"][k])], gold["grad_s::" + k])
         assert e < 6e-2, (k, e)
+    _against_the_references_own_bf16_gradients(cfg, sd, tsv_rows, batch, gv, gold, meta)
+
+
+def _against_the_references_own_bf16_gradients(cfg, sd, tsv_rows, batch, gv, gold, meta):
+    """Round 4: the evidence standard of the loss-curve row applied to the GRADIENTS. g16 holds, for every one of the 207
+    gradient tensors of this very case, how far the REFERENCE's own reduced-precision backward (its forward under
+    torch.autocast(bf16), the mixed precision a CPU offers; the reference trains with fp16=True) lands from its fp32
+    backward: relative L2 error per tensor. The HIP gradients are measured the same way - against the full fp32 gradients,
+    which the oracle recomputes here (it equals the reference to 1e-6: tests/test_oracle_golden.py) - and held to a multiple
+    of the reference's own error, tensor by tensor. The multiple is not 1: autocast keeps LayerNorm, softmax, the residual
+    stream and every saved activation in fp32 and rounds only the matmul operands, while the HIP step keeps the residual
+    stream and all saved activations in bf16 (that is what makes 64 x 512 tokens x 12 layers fit and run at the rate it
+    does); the printed distribution says what that costs."""
+    import json
+    import os
+
+    from tests.golden_util import GOLDEN
+
+    env = dict(np.load(os.path.join(GOLDEN, "g16_shapetrue_bf16.npz")))
+    with open(os.path.join(GOLDEN, "g16_shapetrue_bf16.json")) as f:
+        names = json.load(f)["grad_names"]
+    assert names == meta["grad_names"]
+    with torch.no_grad():
+        table = orc.build_kg_table(tsv_rows, orc.special_vectors(sd, cfg))
+    ref = orc.train_step(dict(sd), cfg, table, batch, orc.AdamState(), max_grad_norm=0.0, base_lr=0.0)["grads"]
+    rows = []
+    for k, ref_err in zip(names, env["grad_relerr_bf16"]):
+        hip_err = _rel(gv[k], ref[k])
+        rows.append((k, hip_err, float(ref_err)))
+    ratios = np.array([h / max(r, 1e-6) for k, h, r in rows if not k.endswith("key.bias")])   # (key.bias: analytically zero)
+    worst = sorted(rows, key=lambda t: -t[1] / max(t[2], 1e-6))[:5]
+    print(f"per-tensor gradient error, HIP / reference-bf16-autocast (both against fp32), {len(ratios)} tensors: median ratio "
+          f"{np.median(ratios):.2f}, 90th percentile {np.percentile(ratios, 90):.2f}, max {ratios.max():.2f}; HIP error median "
+          f"{np.median([h for _, h, _ in rows]):.3e} max {max(h for k, h, _ in rows if not k.endswith('key.bias')):.3e}; reference "
+          f"bf16 median {np.median(env['grad_relerr_bf16']):.3e} max {np.max(env['grad_relerr_bf16'][[not k.endswith('key.bias') for k in names]]):.3e}")
+    print("  worst ratios:", [(k, f"{h:.3e}", f"{r:.3e}") for k, h, r in worst])
+    # the sampled slices of g3: the reference's bf16 gradients themselves are in the fixture
+    for k in meta["grad_keys"]:
+        sl = _slice_of(meta["grad_slices"][k])
+        print(f"  slice {k}: HIP {_rel(gv[k][sl], gold['grad_s::' + k]):.3e}, reference bf16 "
+              f"{_rel(env['grad_s_bf16::' + k], gold['grad_s::' + k]):.3e}")
+    assert np.median(ratios) <= _GRAD_ENVELOPE["median"], np.median(ratios)
+    assert ratios.max() <= _GRAD_ENVELOPE["max"], worst[0]
+
+
+# multiples of the reference's own bf16-autocast gradient error the HIP gradients are held to (set from the numbers the test
+# prints on MI355X; DESIGN.md section 2 states them and why they are not 1)
+_GRAD_ENVELOPE = {"median": 6.0, "max": 12.0}
 
 
 def _chunked_oracle_step(sd, cfg, table, batch, chunk):
@@ -310,6 +358,83 @@ def test_config5_classification_head_on_the_12_layer_encoder(hip):
                    round(float(torch.nn.functional.cosine_similarity(a, r, dim=0)), 4), round(float(a.norm() / r.norm()), 4))
     print("config 5 gradients (relative error, cosine, norm ratio):", errs)
     assert all(e < 0.15 and c > 0.99 and abs(n - 1) < 0.03 for e, c, n in errs.values()), errs
+
+
+def test_config5_on_12_layers_against_the_reference_and_its_own_bf16_run(hip):
+    """BASELINE.json configs[4] at the real depth against REFERENCE-made vectors (g17: the reference's
+    STonKGsForSequenceClassification, ref:stonkgs_finetuning.py:237-346, at 12L / 768h / 12 heads / S 512, a ragged batch of
+    three; oracle/make_golden.py bf16_grads): loss and logits of its fp32 run, the fp32 gradient norm of every tensor, sampled
+    gradient slices - and, per tensor, how far the reference's own bf16-autocast backward lands from its fp32 one, which is
+    what the HIP gradients (full tensors, against the oracle's fp32 autograd) are held to a multiple of."""
+    import json
+    import os
+
+    from stonkgs_amd.config import STonKGsConfig
+    from stonkgs_amd.stonkgs_model import STonKGsForSequenceClassification
+    from tests.golden_util import GOLDEN
+
+    with open(os.path.join(GOLDEN, "g17_cls_shapetrue.json")) as f:
+        meta = json.load(f)
+    gold = dict(np.load(os.path.join(GOLDEN, "g17_cls_shapetrue.npz")))
+    cfg = orc.OracleConfig(**meta["config"])
+    sd = orc.init_state_dict(cfg, seed=meta["weight_seed"])
+    assert abs(float(sum(v.double().abs().sum() for v in sd.values())) - meta["weights_checksum"]) <= 1e-9 * meta["weights_checksum"]
+    gw = torch.Generator().manual_seed(meta["classifier_seed"])
+    sd["classifier.weight"] = (torch.randn(meta["num_labels"], cfg.hidden_size, generator=gw) * 0.02).to(torch.bfloat16).float()
+    sd["classifier.bias"] = (torch.randn(meta["num_labels"], generator=gw) * 0.02).to(torch.bfloat16).float()
+    g = torch.Generator().manual_seed(meta["table_seed"])
+    tsv_rows = torch.randn(cfg.kg_vocab_size, cfg.hidden_size, generator=g, dtype=torch.float64) * meta["table_std"]
+    inputs = {k: torch.from_numpy(gold[k]) for k in ("input_ids", "attention_mask", "token_type_ids")}
+    labels = torch.from_numpy(gold["labels"])
+    c = STonKGsConfig(**meta["config"], hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, num_labels=meta["num_labels"])
+    model = STonKGsForSequenceClassification(c, kg_embeddings=tsv_rows)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all("decoder" in k for k in missing)
+    model.train()
+    loss = float(model.forward_backward(dict(inputs, labels=labels)))
+    model.engine.join_wgrad()
+    model.engine.check_errors()
+    model.eval()
+    with torch.no_grad():
+        out = model(**inputs, return_dict=True)
+    model.train()
+    dl, dl16 = abs(loss - float(gold["loss_fp32"])), abs(float(gold["loss_bf16_autocast"]) - float(gold["loss_fp32"]))
+    print(f"config 5 at 12L/768: loss HIP {loss:.5f} reference fp32 {float(gold['loss_fp32']):.5f} (|d| {dl:.2e}; the reference's "
+          f"own bf16 run {dl16:.2e}); logits rel {_rel(out.logits, gold['logits_fp32']):.2e} (reference bf16 "
+          f"{_rel(gold['logits_bf16_autocast'], gold['logits_fp32']):.2e})")
+    assert dl < 5e-3 and _rel(out.logits, gold["logits_fp32"]) < 3e-2
+    gv = model.named_grad_views()
+    names = meta["grad_names"]
+    for k, ref_norm in zip(names, gold["grad_norms"]):                       # every gradient tensor, by its norm
+        if ref_norm >= 1e-5:
+            assert abs(float(gv[k].double().norm()) - ref_norm) < 4e-2 * ref_norm, (k, float(gv[k].double().norm()), ref_norm)
+    # full tensors against the oracle's fp32 autograd, next to the reference's own bf16 error for the same tensor
+    params = {k: sd[k].clone().requires_grad_(True) for k in names}
+    work = dict(sd)
+    work.update(params)
+    with torch.no_grad():
+        table = orc.build_kg_table(tsv_rows, orc.special_vectors(sd, cfg))
+    ref = orc.forward_classification(work, cfg, table, **inputs, labels=labels)
+    ref["loss"].backward()
+    assert abs(float(ref["loss"]) - float(gold["loss_fp32"])) < 1e-5          # (the oracle IS the reference here)
+    rows = [(k, _rel(gv[k], params[k].grad), float(r)) for k, r in zip(names, gold["grad_relerr_bf16"])]
+    ratios = np.array([h / max(r, 1e-6) for k, h, r in rows if not k.endswith("key.bias")])
+    worst = sorted(rows, key=lambda t: -t[1] / max(t[2], 1e-6))[:5]
+    print(f"config 5 per-tensor gradient error, HIP / reference-bf16-autocast (both against fp32), {len(ratios)} tensors: median "
+          f"ratio {np.median(ratios):.2f}, 90th percentile {np.percentile(ratios, 90):.2f}, max {ratios.max():.2f}; HIP error "
+          f"median {np.median([h for _, h, _ in rows]):.3e}, reference bf16 median {np.median(gold['grad_relerr_bf16']):.3e}")
+    print("  worst ratios:", [(k, f"{h:.3e}", f"{r:.3e}") for k, h, r in worst])
+    for k in meta["grad_keys"]:
+        sl = _slice_of(meta["grad_slices"][k])
+        print(f"  slice {k}: HIP {_rel(gv[k][sl], gold['grad_s::' + k]):.3e}, reference bf16 "
+              f"{_rel(gold['grad_s_bf16::' + k], gold['grad_s::' + k]):.3e}")
+    assert np.median(ratios) <= _GRAD_ENVELOPE_CLS["median"], np.median(ratios)
+    assert ratios.max() <= _GRAD_ENVELOPE_CLS["max"], worst[0]
+
+
+# as _GRAD_ENVELOPE, for the three-sample classification step (every gradient is the sum of three rows' contributions: no
+# averaging over hundreds of labelled rows)
+_GRAD_ENVELOPE_CLS = {"median": 6.0, "max": 12.0}
 
 
 def test_bench_configuration_packed_step_equals_padded_step(hip):

@@ -114,17 +114,24 @@ def test_loss_curve_within_the_references_own_mixed_precision_envelope(hip, name
     # (a wrong dropout scale, a biased gradient) from that shared sensitivity. (2) The first ten steps against the fp32
     # run, before divergence has amplified anything.
     t = got - ref16
-    early = np.abs(d[:10]).max()
+    early, early16 = np.abs(d[:10]).max(), np.abs(t[:10]).max()
     print(f"  HIP vs reference bf16 autocast: max |d| {np.abs(t).max():.3e} (step {int(np.abs(t).argmax())}), rms "
-          f"{np.sqrt((t ** 2).mean()):.3e}, mean {t.mean():+.3e} | first ten steps vs fp32: HIP max {early:.3e}, "
-          f"reference bf16 {np.abs(e[:10]).max():.3e}")
+          f"{np.sqrt((t ** 2).mean()):.3e}, mean {t.mean():+.3e} | first ten steps: HIP vs fp32 max {early:.3e} (reference bf16 vs "
+          f"fp32 {np.abs(e[:10]).max():.3e}), HIP vs reference bf16 max {early16:.3e}")
     lim = _TRACK_BOUNDS[name]
     assert np.sqrt((t ** 2).mean()) <= lim["rms_vs_bf16"] * np.sqrt((e ** 2).mean()), "HIP does not track the reference's bf16 run"
     assert np.abs(t).max() <= lim["max_vs_bf16"] * np.abs(e).max()
     assert early <= lim["early"], "the first ten steps already leave the fp32 run"
+    assert early16 <= lim["early_vs_bf16"], "the first ten steps already leave the reference's bf16 run"
 
 
-# bounds of the round-4 assertions above, from the numbers the test prints (tests run on MI355X, round 4):
-#   g12 (small, 200 steps): see DESIGN.md section 2; g11 (real shape, 60 steps, batches of two): likewise
-_TRACK_BOUNDS = {"g12_curve_small": {"rms_vs_bf16": 2.0, "max_vs_bf16": 2.0, "early": 8e-3},
-                 "g11_curve_shapetrue": {"rms_vs_bf16": 2.0, "max_vs_bf16": 2.0, "early": 0.5}}
+# Bounds of the round-4 assertions above, as multiples of the reference's own |bf16 - fp32| envelope, from what the test
+# prints on MI355X (round 4):
+#   g11 (real shape, batches of two - the sensitive trajectory): HIP vs the reference's bf16 run max 5.1e-2 / rms 1.0e-2, i.e.
+#     0.048 / 0.049 of the envelope (1.065 / 0.2115) that BOTH keep from the fp32 run: the two reduced-precision runs move
+#     together, and a numerical fault of the size the factor-2 envelope check would let through (tenths of a loss unit) fails
+#     here; bound = three times the measured share. First ten steps vs fp32: 0.171 (the reference's bf16 run: 0.184).
+#   g12 (small shape): the deviations are independent rounding noise (HIP vs reference bf16 1.6 / 1.5 of the envelope, no
+#     tracking to exploit); the early steps are the tight check there: 1.2e-3 in the first ten (reference bf16: 1.4e-3).
+_TRACK_BOUNDS = {"g12_curve_small": {"rms_vs_bf16": 2.0, "max_vs_bf16": 2.0, "early": 4e-3, "early_vs_bf16": 6e-3},
+                 "g11_curve_shapetrue": {"rms_vs_bf16": 0.15, "max_vs_bf16": 0.15, "early": 0.3, "early_vs_bf16": 6e-2}}

@@ -252,6 +252,36 @@ int stonk_adamw_step(float* p, float* g, float* m, float* v, void* p_bf16, int64
                      void* stream);
 int stonk_scale_f32(float* x, int64_t n, float s, void* stream);
 
+/* ---- Data-parallel gradient exchange (csrc/comm.hip): RCCL collectives on a stream the LIBRARY owns, handed over by
+ * events. Replaces torch DistributedDataParallel's bucketed all-reduce, which the reference gets from HF Trainer when it
+ * is launched distributed (ref:src/stonkgs/models/stonkgs_pretraining.py:215-223), and - reduce-scatter / all-gather -
+ * DeepSpeed ZeRO-2's exchange when `deepspeed=True` (:174-175).
+ *
+ *   stonk_comm_unique_id   rank 0 fills 128 bytes (an ncclUniqueId); the CALLER carries them to the other ranks (a file,
+ *                          a socket, torch's store - the library opens no connection of its own for that);
+ *   stonk_comm_init        one communicator per process (one process per GPU): RCCL over xGMI inside a node; creates the
+ *                          communicator's stream and two events. `*comm_out` is an opaque handle;
+ *   stonk_comm_*_async     `buf` / `send` / `recv` are device pointers, `n` counts ELEMENTS, dtype 0 = fp32, 1 = bf16, the
+ *                          reduction is a sum (the mean is the optimizer's grad_scale). The collective is ordered behind
+ *                          everything `after_stream` has enqueued at the call (event hand-off: the producer stream does
+ *                          not wait, the host does not block) and runs on the communicator's stream. allreduce: in place.
+ *                          reduce_scatter: send holds world * recv_n elements, recv (which may be the rank's own slice of
+ *                          send) receives the sum of slice `rank`; allgather: recv holds world * send_n elements (send
+ *                          may be the rank's own slice of recv);
+ *   stonk_comm_wait        `stream` waits (on the device) for every collective issued so far; no host synchronisation;
+ *   stonk_comm_stream      the communicator's hipStream_t (for a profiler range, or to order caller work behind it);
+ *   stonk_comm_destroy     drains the stream, destroys communicator, stream and events.
+ * Return codes as everywhere (0, STONK_E*, a hipError_t); an RCCL failure r is reported as 10000 + r. RCCL itself is
+ * resolved at run time: without it these entry points return STONK_EINVAL and the rest of the library is unaffected. */
+int stonk_comm_unique_id(void* id_out_128_bytes);
+int stonk_comm_init(void** comm_out, int world, int rank, const void* unique_id_128_bytes, int device);
+int stonk_comm_allreduce_async(void* comm, void* buf, int64_t n, int dtype, void* after_stream);
+int stonk_comm_reduce_scatter_async(void* comm, const void* send, void* recv, int64_t recv_n, int dtype, void* after_stream);
+int stonk_comm_allgather_async(void* comm, const void* send, void* recv, int64_t send_n, int dtype, void* after_stream);
+int stonk_comm_wait(void* comm, void* stream);
+void* stonk_comm_stream(void* comm);
+int stonk_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,14 @@ _SIGNATURES = {
     "stonk_adamw_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _f32, _f32,
                          _vp, _i32, _i64, _vp],
     "stonk_scale_f32": [_vp, _i64, _f32, _vp],
+    # data-parallel gradient exchange: RCCL on a library-owned stream (csrc/comm.hip)
+    "stonk_comm_unique_id": [_vp],
+    "stonk_comm_init": [C.POINTER(C.c_void_p), _i32, _i32, _vp, _i32],
+    "stonk_comm_allreduce_async": [_vp, _vp, _i64, _i32, _vp],
+    "stonk_comm_reduce_scatter_async": [_vp, _vp, _vp, _i64, _i32, _vp],
+    "stonk_comm_allgather_async": [_vp, _vp, _vp, _i64, _i32, _vp],
+    "stonk_comm_wait": [_vp, _vp],
+    "stonk_comm_destroy": [_vp],
 }
 
 
@@ -121,13 +129,15 @@ def lib():
         handle.stonk_sumsq_workspace_floats.restype = C.c_int64
         handle.stonk_unpad_workspace_ints.argtypes = [_i32]
         handle.stonk_unpad_workspace_ints.restype = C.c_int64
+        handle.stonk_comm_stream.argtypes = [_vp]
+        handle.stonk_comm_stream.restype = C.c_void_p
         _lib = handle
     return _lib
 
 
 def exported_symbols():
     return sorted(list(_SIGNATURES) + ["stonk_abi_version", "stonk_layernorm_bwd_workspace_floats",
-                                     "stonk_sumsq_workspace_floats", "stonk_unpad_workspace_ints"])
+                                     "stonk_sumsq_workspace_floats", "stonk_unpad_workspace_ints", "stonk_comm_stream"])
 
 
 def check(status: int, name: str) -> None:

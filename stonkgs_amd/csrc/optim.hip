@@ -55,13 +55,40 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   }
 }
 
-// One pass over the flat buffers: p, g, m, v read; p, m, v, bf16(p) written; g zeroed.
+// One pass over the flat buffers: p, g, m, v read; p, m, v, bf16(p) written; g zeroed - 34 bytes per parameter, each touched
+// once per step (8.3 GB at 243 M parameters: nothing a cache could keep). HBM-bound. Round 4 (tools/adamw_ab.py, 243 M
+// elements, one box): 1, 2 or 4 groups requested per thread before the first use, default or non-temporal accesses -
+// 4.30 / 4.41 / 4.27 TB/s and 4.25 / 4.39 / 4.40: the mix of four read and five write streams runs at 4.3-4.4 TB/s whatever
+// a thread keeps in flight (a plain copy reaches 6.3 on this chip). Two groups, default policy.
+#ifndef STONK_ADAMW_UNROLL
+#define STONK_ADAMW_UNROLL 2
+#endif
+#ifndef STONK_ADAMW_NT
+#define STONK_ADAMW_NT 0
+#endif
+template <typename T>
+__device__ __forceinline__ T stream_load(const T* q) {
+#if STONK_ADAMW_NT
+  return __builtin_nontemporal_load(q);
+#else
+  return *q;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void stream_store(T* q, const T& x) {
+#if STONK_ADAMW_NT
+  __builtin_nontemporal_store(x, q);
+#else
+  *q = x;
+#endif
+}
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16* __restrict__ pb, long n, float lr,
                                                     float b1, float b2, float eps, float wd, float bc1, float bc2,
                                                     const float* __restrict__ gnorm_sq, float max_norm,
                                                     float grad_scale, const long* __restrict__ decay_spans,
                                                     int n_spans, long span_base) {
+  constexpr int U = STONK_ADAMW_UNROLL;
   float coef = grad_scale;
   if (gnorm_sq && max_norm > 0.f) {
     // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
@@ -72,39 +99,55 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   const float step = lr / bc1;
   const float inv_sqrt_bc2 = rsqrtf(bc2);
   const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    f32x4 pp = *(f32x4*)(p + 4 * i), gg = *(f32x4*)(g + 4 * i), mm = *(f32x4*)(m + 4 * i), vv = *(f32x4*)(v + 4 * i);
-    bf16x4 o;
-    // decoupled weight decay: everywhere (no table), or on the elements inside one of the sorted [lo, hi) spans of the
-    // flat buffer (HF Trainer's grouping: weights yes, biases and LayerNorm no). Tensors start at multiples of 256
-    // elements, so the four elements of a group share the answer.
-    float keep = 1.f - lr * wd;
-    if (decay_spans && wd != 0.f) {
-      const long e = span_base + 4 * i;
-      int lo = 0, hi = n_spans;
-      while (lo < hi) {   // last span whose start <= e
-        const int mid = (lo + hi) >> 1;
-        if (decay_spans[2 * mid] <= e) lo = mid + 1;
-        else hi = mid;
+  const long stride = (long)gridDim.x * 256;
+  for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += stride * U) {
+    f32x4 pp[U], gg[U], mm[U], vv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = i0 + u * stride;
+      if (i < n4) {
+        pp[u] = stream_load((const f32x4*)(p + 4 * i));
+        gg[u] = stream_load((const f32x4*)(g + 4 * i));
+        mm[u] = stream_load((const f32x4*)(m + 4 * i));
+        vv[u] = stream_load((const f32x4*)(v + 4 * i));
       }
-      if (lo == 0 || e >= decay_spans[2 * (lo - 1) + 1]) keep = 1.f;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float gr = gg[j] * coef;
-      float w = pp[j] * keep;
-      mm[j] = b1 * mm[j] + (1.f - b1) * gr;
-      vv[j] = b2 * vv[j] + (1.f - b2) * gr * gr;
-      const float denom = sqrtf(vv[j]) * inv_sqrt_bc2 + eps;
-      w -= step * (mm[j] / denom);
-      pp[j] = w;
-      o[j] = (bf16)w;
+    for (int u = 0; u < U; ++u) {
+      const long i = i0 + u * stride;
+      if (i >= n4) break;
+      bf16x4 o;
+      // decoupled weight decay: everywhere (no table), or on the elements inside one of the sorted [lo, hi) spans of the
+      // flat buffer (HF Trainer's grouping: weights yes, biases and LayerNorm no). Tensors start at multiples of 256
+      // elements, so the four elements of a group share the answer.
+      float keep = 1.f - lr * wd;
+      if (decay_spans && wd != 0.f) {
+        const long e = span_base + 4 * i;
+        int lo = 0, hi = n_spans;
+        while (lo < hi) {   // last span whose start <= e
+          const int mid = (lo + hi) >> 1;
+          if (decay_spans[2 * mid] <= e) lo = mid + 1;
+          else hi = mid;
+        }
+        if (lo == 0 || e >= decay_spans[2 * (lo - 1) + 1]) keep = 1.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gr = gg[u][j] * coef;
+        float w = pp[u][j] * keep;
+        mm[u][j] = b1 * mm[u][j] + (1.f - b1) * gr;
+        vv[u][j] = b2 * vv[u][j] + (1.f - b2) * gr * gr;
+        const float denom = sqrtf(vv[u][j]) * inv_sqrt_bc2 + eps;
+        w -= step * (mm[u][j] / denom);
+        pp[u][j] = w;
+        o[j] = (bf16)w;
+      }
+      stream_store((f32x4*)(p + 4 * i), pp[u]);
+      stream_store((f32x4*)(m + 4 * i), mm[u]);
+      stream_store((f32x4*)(v + 4 * i), vv[u]);
+      stream_store((f32x4*)(g + 4 * i), (f32x4){0.f, 0.f, 0.f, 0.f});
+      if (pb) *(bf16x4*)(pb + 4 * i) = o;   // (read again by the next forward: default policy)
     }
-    *(f32x4*)(p + 4 * i) = pp;
-    *(f32x4*)(m + 4 * i) = mm;
-    *(f32x4*)(v + 4 * i) = vv;
-    *(f32x4*)(g + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (pb) *(bf16x4*)(pb + 4 * i) = o;
   }
 }
 

@@ -58,6 +58,13 @@ class TrainingArguments:
     # 1/world piece of every bucket only, and the updated fp32 parameters are all-gathered (same bytes on the wire as the
     # all-reduce; AdamW's 30 B/param of HBM traffic and the optimizer state shrink by the world size)
     shard_optimizer: bool = False
+    # sum(g^2) for the clip coefficient per gradient bucket as backward finalises it (beside matrix work), instead of one
+    # pass over the whole buffer between backward and AdamW
+    bucket_grad_norm: bool = True
+    # who runs the gradient collectives: "torch" = torch.distributed's process group (backend nccl = RCCL), "stonk" = the C
+    # ABI's own communicator (stonk_comm_*: RCCL on a library-owned stream with event hand-off; torch.distributed, if
+    # initialised, only carries the 128-byte RCCL id once)
+    comm_backend: str = "torch"
 
 
 def linear_schedule_lr(base_lr: float, step: int, max_steps: int, warmup: int = 0) -> float:
@@ -205,7 +212,7 @@ class GradSynchronizer:
     that divides 64 cuts them into 16-byte aligned pieces."""
 
     def __init__(self, grad: torch.Tensor, segments: Dict[str, int], bucket_mb: float = 64.0, group=None,
-                 force: bool = False, shard: bool = False):
+                 force: bool = False, shard: bool = False, comm=None):
         """`force`: issue the collectives even in a one-rank group (a sum over one rank: the values do not change) - lets
         a one-GPU box execute the RCCL path, its stream ordering and the kernel routing that goes with it."""
         import torch.distributed as dist
@@ -213,9 +220,16 @@ class GradSynchronizer:
         self.dist = dist
         self.grad = grad
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.active = self.world > 1 or (force and dist.is_initialized())
+        # `comm`: a stonkgs_amd.comm.StonkComm - the collectives then go through the C ABI's own communicator (RCCL on the
+        # library's stream, event hand-off) instead of torch.distributed
+        self.comm = comm
+        if comm is not None:
+            self.world, self.rank = comm.world, comm.rank
+            self.active = self.world > 1 or force
+        else:
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+            self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+            self.active = self.world > 1 or (force and dist.is_initialized())
         self.segment_end = dict(segments)  # notification name -> end offset in the flat buffer
         ends = sorted(set(segments.values()))
         self.buckets = plan_buckets(ends, int(bucket_mb * (1 << 20) / 4))
@@ -227,9 +241,50 @@ class GradSynchronizer:
                                  "aligned pieces (tensors start at multiples of 256 elements: use a world size dividing 64)")
             # gloo (CPU tests, several ranks on one card) has no reduce-scatter: an all-reduce leaves the sum in the owned
             # piece as well - same result, more bytes, never a measurement
-            self._has_rs = dist.get_backend(group) == "nccl"
+            self._has_rs = comm is not None or dist.get_backend(group) == "nccl"
         self._next = 0
         self._works = []
+        self._norm_parts = None    # per-bucket sums of squares of the FINAL gradient (enable_bucket_norm)
+
+    # ---- the gradient norm, bucket by bucket (round 4). The clip coefficient needs sum(g^2) over the whole buffer: a 974-MB
+    # read that sat between the end of backward and AdamW (0.26 ms of the step's serial tail). A bucket's gradients are
+    # final long before that - when backward reports the segment ending there (after the bucket's collective at N > 1) - so
+    # its partial sum is taken THEN, on the weight-gradient stream (N = 1) or on a stream of its own behind the collective,
+    # beside matrix work that leaves HBM idle. Partials are summed in bucket order: the same bits on every replica.
+    def enable_bucket_norm(self) -> None:
+        dev = self.grad.device
+        if dev.type != "cuda" or self._norm_parts is not None:
+            return
+        nws = int(hip.lib().stonk_sumsq_workspace_floats())
+        self._norm_parts = torch.zeros(len(self.buckets), dtype=torch.float32, device=dev)
+        self._norm_ws = torch.zeros(len(self.buckets), nws, dtype=torch.float32, device=dev)   # (one per bucket: launches overlap)
+        self._norm_stream = torch.cuda.Stream(device=dev) if self.active else None
+
+    def _bucket_norm(self, b: int, work) -> None:
+        lo, hi = self.buckets[b]
+        if self.shard:
+            piece = (hi - lo) // self.world
+            lo, hi = lo + self.rank * piece, lo + (self.rank + 1) * piece
+        args = (self.grad.data_ptr() + 4 * lo, hi - lo, self._norm_parts.data_ptr() + 4 * b, self._norm_ws[b].data_ptr(),
+                self._norm_ws.shape[1])
+        if work is None:
+            hip.call("stonk_sumsq_f32", *args, hip.stream_ptr())
+            return
+        self._norm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._norm_stream):
+            work.wait()                       # the norm stream is ordered behind the collective, nobody else waits here
+            hip.call("stonk_sumsq_f32", *args, hip.stream_ptr())
+
+    def take_grad_norm_sq(self, out: torch.Tensor) -> bool:
+        """After `finish()`: `out[0]` = sum of the bucket partials (this rank's pieces when sharded), in bucket order.
+        False when the partials are not kept (CPU tensors): the caller then reads the buffer itself."""
+        if self._norm_parts is None:
+            return False
+        if self._norm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._norm_stream)
+        torch.sum(self._norm_parts, dim=0, keepdim=True, out=out)
+        self._norm_parts.zero_()
+        return True
 
     def owned_spans(self) -> Optional[List[tuple]]:
         """[lo, hi) pieces of the flat buffers this rank reduces into and updates; None when the optimizer is replicated."""
@@ -243,28 +298,45 @@ class GradSynchronizer:
 
     def _launch(self, lo: int, hi: int):
         d = self.dist
+        if self.comm is not None:
+            from .comm import _Work
+
+            if self.shard:
+                piece = (hi - lo) // self.world
+                self.comm.reduce_scatter(self.grad[lo + self.rank * piece: lo + (self.rank + 1) * piece], self.grad[lo:hi])
+            else:
+                self.comm.all_reduce(self.grad[lo:hi])
+            return _Work(self.comm)
         if self.shard and self._has_rs:
             piece = (hi - lo) // self.world
             mine = self.grad[lo + self.rank * piece: lo + (self.rank + 1) * piece]   # in place: output = own slice of input
             return d.reduce_scatter_tensor(mine, self.grad[lo:hi], op=d.ReduceOp.SUM, group=self.group, async_op=True)
         return d.all_reduce(self.grad[lo:hi], op=d.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def _bucket_final(self) -> None:
+        b = self._next
+        work = None
+        if self.active:
+            work = self._launch(*self.buckets[b])
+            self._works.append(work)
+        if self._norm_parts is not None:
+            self._bucket_norm(b, work)
+        self._next += 1
+
     def on_segment_done(self, name: str) -> None:
-        if not self.active:
+        if not self.active and self._norm_parts is None:
             return
         end = self.segment_end.get(name)
         if end is None:
             return
         while self._next < len(self.buckets) and self.buckets[self._next][1] <= end:
-            self._works.append(self._launch(*self.buckets[self._next]))
-            self._next += 1
+            self._bucket_final()
 
     def finish(self) -> float:
         """Flush remaining buckets, wait for all of them; returns the factor that turns the sum into the mean."""
-        if self.active:
+        if self.active or self._norm_parts is not None:
             while self._next < len(self.buckets):
-                self._works.append(self._launch(*self.buckets[self._next]))
-                self._next += 1
+                self._bucket_final()
             for w in self._works:
                 w.wait()
         self._works, self._next = [], 0
@@ -272,7 +344,10 @@ class GradSynchronizer:
 
     def all_reduce_scalar(self, t: torch.Tensor) -> None:
         """Sum a small tensor over the ranks (the sharded grad-norm: every rank holds the squares of its pieces)."""
-        if self.shard:
+        if self.shard and self.comm is not None:
+            self.comm.all_reduce(t)
+            self.comm.wait()
+        elif self.shard:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def gather_params(self, flat: torch.Tensor) -> None:
@@ -284,6 +359,9 @@ class GradSynchronizer:
         for lo, hi in self.buckets:
             piece = (hi - lo) // self.world
             mine = flat[lo + self.rank * piece: lo + (self.rank + 1) * piece]
+            if self.comm is not None:
+                self.comm.all_gather(flat[lo:hi], mine)
+                continue
             if self._has_rs:
                 works.append(d.all_gather_into_tensor(flat[lo:hi], mine, group=self.group, async_op=True))
             else:   # gloo: list form, into the bucket's own pieces
@@ -291,6 +369,8 @@ class GradSynchronizer:
                 works.append(d.all_gather(outs, mine.clone(), group=self.group, async_op=True))
         for w in works:
             w.wait()
+        if self.comm is not None:
+            self.comm.wait()
 
 
 def segment_ends_for(model) -> Dict[str, int]:
@@ -323,11 +403,21 @@ class Trainer:
         self.data_collator = data_collator
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        comm = None
+        if self.args.comm_backend == "stonk":
+            from .comm import StonkComm
+
+            comm = StonkComm(self.rank, self.world, model.device.index or 0)
+        elif self.args.comm_backend != "torch":
+            raise ValueError("comm_backend must be 'torch' or 'stonk'")
+        self.comm = comm
         self.sync = GradSynchronizer(model._store.grad, segment_ends_for(model), self.args.ddp_bucket_mb,
-                                     force=self.args.ddp_force_collectives, shard=self.args.shard_optimizer)
+                                     force=self.args.ddp_force_collectives, shard=self.args.shard_optimizer, comm=comm)
         self.optimizer = FusedAdamW(model._store, (self.args.adam_beta1, self.args.adam_beta2), self.args.adam_epsilon,
                                     self.args.weight_decay, self.args.max_grad_norm, spans=self.sync.owned_spans())
         model.engine.comm_overlap = self.sync.active   # (see Engine.comm_overlap)
+        if self.args.bucket_grad_norm:
+            self.sync.enable_bucket_norm()
         self.global_step = 0
         self._micro = 0
         self._next_cache = None
@@ -370,7 +460,8 @@ class Trainer:
                 scale = self.sync.finish()
                 opt = self.optimizer
                 opt.step_count += 1
-                opt.accumulate_grad_norm_sq()               # replicated: the whole buffer; sharded: this rank's pieces ...
+                if not self.sync.take_grad_norm_sq(opt.gnorm_sq):   # (bucket partials taken during backward)
+                    opt.accumulate_grad_norm_sq()           # replicated: the whole buffer; sharded: this rank's pieces ...
                 self.sync.all_reduce_scalar(opt.gnorm_sq)   # ... summed over the ranks (a no-op when replicated)
                 opt.apply_update(lr, grad_scale=scale)
                 if self.sync.shard:

@@ -88,6 +88,114 @@ def test_rccl_path_executes_in_a_one_rank_group(hip):
     assert float((p2 - p0).abs().max()) <= 2.1e-3 and cos2 > 0.999, (float((p2 - p0).abs().max()), cos2)
 
 
+def test_stonk_comm_c_abi_in_a_one_rank_group(hip):
+    """`stonk_comm_*` (RCCL on a library-owned stream, event hand-off) on the one-GPU box: a one-rank
+    communicator - the collectives execute, a sum over one rank leaves the values as they are. Checked: the comm stream is
+    ordered BEHIND the producer stream (the all-reduce sees what a kernel queued just before it wrote), the consumer stream
+    behind the comm stream, reduce-scatter / all-gather into the rank's own slice in place, both dtypes; and the training
+    step on this backend (all-reduce and sharded) equals the plain step."""
+    from stonkgs_amd.comm import StonkComm
+    from stonkgs_amd.config import STonKGsConfig
+    from stonkgs_amd.data import synthetic_batch
+    from stonkgs_amd.stonkgs_model import STonKGsForPreTraining
+    from stonkgs_amd.stonkgs_pretraining import Trainer, TrainingArguments
+
+    comm = StonkComm(0, 1, torch.cuda.current_device())
+    assert comm.stream_ptr not in (0, torch.cuda.current_stream().cuda_stream)
+    n = 64 << 20
+    x = torch.zeros(n, device="cuda")
+    big = torch.randn(8192, 8192, device="cuda")
+    for _ in range(3):
+        big = big @ big * 1e-4                       # keeps the producer stream busy: the fill below is queued, not done
+    x.fill_(3.0)
+    comm.all_reduce(x)
+    comm.wait()
+    y = x * 2
+    torch.cuda.synchronize()
+    assert float(y.min()) == 6.0 and float(y.max()) == 6.0
+    h = torch.arange(4096, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    comm.all_reduce(h)
+    recv = torch.empty(4096, device="cuda")
+    send = torch.arange(4096, device="cuda", dtype=torch.float32)
+    comm.reduce_scatter(recv, send)
+    comm.reduce_scatter(send[:4096], send)           # in place: the rank's own slice of the input
+    out = torch.zeros(4096, device="cuda")
+    comm.all_gather(out, recv)
+    comm.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(recv, send) and torch.equal(out, send) and torch.equal(h.float(), torch.arange(4096, device="cuda").to(torch.bfloat16).float())
+    comm.close()
+
+    cfg = STonKGsConfig(vocab_size=2048, kg_vocab_size=640, num_hidden_layers=2, hidden_dropout_prob=0.0,
+                        attention_probs_dropout_prob=0.0)
+    table = torch.randn(640, cfg.hidden_size, generator=torch.Generator().manual_seed(5), dtype=torch.float64) * 0.3
+    B = 32
+    batches = [synthetic_batch(B, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=100 + i) for i in range(2)]
+    init = STonKGsForPreTraining(cfg, kg_embeddings=table, seed=0)._store.data.detach().clone()
+
+    def run(backend, force, shard=False):
+        model = STonKGsForPreTraining(cfg, kg_embeddings=table, seed=0)
+        tr = Trainer(model, TrainingArguments(learning_rate=1e-3, max_steps=10, per_device_train_batch_size=B, ddp_bucket_mb=8,
+                                              ddp_force_collectives=force, shard_optimizer=shard, comm_backend=backend))
+        model.engine.comm_overlap = True
+        losses = [float(tr.training_step(model, b)) for b in batches]
+        model.engine.check_errors()
+        model.engine.wait_params()
+        torch.cuda.synchronize()
+        p = model._store.data.detach().clone()
+        if tr.comm is not None:
+            tr.comm.close()
+        return losses, p, tr
+
+    l0, p0, tr0 = run("torch", False)
+    l1, p1, tr1 = run("stonk", True)
+    assert tr1.sync.active and tr1.sync.comm is not None and len(tr1.sync.buckets) >= 3 and not tr0.sync.active
+    l2, p2, tr2 = run("stonk", True, shard=True)
+    assert tr2.sync.shard
+    for l, p in ((l1, p1), (l2, p2)):
+        assert l == pytest.approx(l0, rel=5e-5)
+        cos = torch.nn.functional.cosine_similarity((p - init).flatten(), (p0 - init).flatten(), dim=0).item()
+        assert float((p - p0).abs().max()) <= 2.1e-3 and cos > 0.999, (float((p - p0).abs().max()), cos)
+
+
+def test_bucket_grad_norm_equals_the_one_pass_norm(hip):
+    """TrainingArguments.bucket_grad_norm (round 4): sum(g^2) taken bucket by bucket as backward finalises them - on the
+    weight-gradient stream - must clip exactly as the one pass over the whole buffer did: same losses, same parameters after
+    two steps (up to the reordering of fp32 atomics that two runs of either show)."""
+    from stonkgs_amd.config import STonKGsConfig
+    from stonkgs_amd.data import synthetic_batch
+    from stonkgs_amd.stonkgs_model import STonKGsForPreTraining
+    from stonkgs_amd.stonkgs_pretraining import Trainer, TrainingArguments
+
+    cfg = STonKGsConfig(vocab_size=2048, kg_vocab_size=640, num_hidden_layers=2, hidden_dropout_prob=0.0,
+                        attention_probs_dropout_prob=0.0)
+    table = torch.randn(640, cfg.hidden_size, generator=torch.Generator().manual_seed(5), dtype=torch.float64) * 0.3
+    B = 32
+    batches = [synthetic_batch(B, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=100 + i) for i in range(2)]
+    init = STonKGsForPreTraining(cfg, kg_embeddings=table, seed=0)._store.data.detach().clone()
+    res = []
+    for flag in (True, False):
+        model = STonKGsForPreTraining(cfg, kg_embeddings=table, seed=0)
+        tr = Trainer(model, TrainingArguments(learning_rate=1e-3, max_steps=10, per_device_train_batch_size=B, ddp_bucket_mb=8,
+                                              bucket_grad_norm=flag))
+        assert (tr.sync._norm_parts is not None) == flag
+        losses, norms = [], []
+        for b in batches:
+            losses.append(float(tr.training_step(model, b)))
+            model.engine.wait_params()
+            norms.append(float(tr.optimizer.gnorm_sq.sqrt()))
+        model.engine.check_errors()
+        torch.cuda.synchronize()
+        res.append((losses, norms, model._store.data.detach().clone()))
+    (l1, n1, p1), (l0, n0, p0) = res
+    assert n1[0] > 1.0                                            # the clip is active: the norm matters
+    # step 1: the same gradients, two summation orders; step 2 sits behind one Adam step on gradients whose fp32 atomics
+    # reorder from run to run (two runs of EITHER form differ by a few 1e-5 there)
+    assert n1[0] == pytest.approx(n0[0], rel=5e-6) and n1[1] == pytest.approx(n0[1], rel=2e-4) and l1 == pytest.approx(l0, rel=5e-5)
+    cos = torch.nn.functional.cosine_similarity((p1 - init).flatten(), (p0 - init).flatten(), dim=0).item()
+    assert float((p1 - p0).abs().max()) <= 2.1e-3 and cos > 0.999
+
+
 def test_two_ranks_on_one_gpu_over_gloo(hip):
     r = _ranks(2, "tools/dp_check.py", env={"STONK_DIST_BACKEND": "gloo"})
     assert r.returncode == 0 and "DP2 OK (gloo)" in r.stdout[0], r.tail()

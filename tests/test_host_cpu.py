@@ -94,7 +94,7 @@ def test_plan_buckets_covers_buffer_exactly():
 def test_library_exports_every_declared_symbol():
     """include/stonk_hip.h, the ctypes table and the built .so agree (no compute call: no GPU here)."""
     header = open(os.path.join(ROOT, "include", "stonk_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|int64_t) (stonk_\w+)\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|void\*) (stonk_\w+)\(", header, flags=re.M))
     assert declared == set(_hip.exported_symbols())
     lib = ctypes.CDLL(_hip.LIB_PATH)
     for name in declared:
@@ -129,6 +129,11 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert lib.stonk_attention_fwd(16, 16, 16, 192, 0, 0, 0, 16, 64, 0, 1, 1, 4224, 64, 0.125, 0.0, 0, 0) == -2    # > 4096 keys: refused
     assert lib.stonk_attention_fwd(16, 16, 16, 192, 0, 16, 0, 16, 64, 0, 1, 1, 512, 64, 0.125, 0.0, 0, 0) == -1
     assert lib.stonk_attention_fwd(16, 16, 16, 192, 16, 0, 16, 16, 64, 0, 1, 1, 512, 64, 0.125, 0.0, 0, 0) == -1  # query limits need the packed layout  # packed rows need a mask
+    # the gradient-exchange entry points: a null communicator / buffer, an unknown dtype
+    assert lib.stonk_comm_allreduce_async(0, 16, 4, 0, 0) == -1 and lib.stonk_comm_wait(0, 0) == -1
+    assert lib.stonk_comm_reduce_scatter_async(0, 16, 16, 4, 0, 0) == -1 and lib.stonk_comm_allgather_async(0, 16, 16, 4, 7, 0) == -1
+    assert lib.stonk_comm_init(None, 1, 0, 0, 0) == -1 and lib.stonk_comm_destroy(0) == -1 and lib.stonk_comm_unique_id(0) == -1
+    assert not lib.stonk_comm_stream(0)
     with pytest.raises(_hip.StonkHipError):
         _hip.check(-2, "x")
 

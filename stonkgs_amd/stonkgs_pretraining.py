@@ -59,8 +59,12 @@ class TrainingArguments:
     # all-reduce; AdamW's 30 B/param of HBM traffic and the optimizer state shrink by the world size)
     shard_optimizer: bool = False
     # sum(g^2) for the clip coefficient per gradient bucket as backward finalises it (beside matrix work), instead of one
-    # pass over the whole buffer between backward and AdamW
-    bucket_grad_norm: bool = True
+    # pass over the whole buffer between backward and AdamW. OFF by default: measured on one GPU (round 4, tools/ab_step.py
+    # args:bucket_grad_norm, interleaved in one process) the step is 0.33 ms LONGER with it (28.30 against 27.97 ms) - the
+    # 0.26-ms serial read goes, but a notification per segment orders the weight-gradient stream behind the main stream
+    # once per layer and a 974-MB read runs beside the GEMMs. Kept for N > 1, where the partial of a bucket can only be
+    # taken behind its collective and the alternative is the same serial pass after the LAST collective.
+    bucket_grad_norm: bool = False
     # who runs the gradient collectives: "torch" = torch.distributed's process group (backend nccl = RCCL), "stonk" = the C
     # ABI's own communicator (stonk_comm_*: RCCL on a library-owned stream with event hand-off; torch.distributed, if
     # initialised, only carries the 128-byte RCCL id once)
@@ -245,6 +249,7 @@ class GradSynchronizer:
         self._next = 0
         self._works = []
         self._norm_parts = None    # per-bucket sums of squares of the FINAL gradient (enable_bucket_norm)
+        self.norm_on = True        # (a per-step switch for A/B runs: Trainer copies TrainingArguments.bucket_grad_norm here)
 
     # ---- the gradient norm, bucket by bucket (round 4). The clip coefficient needs sum(g^2) over the whole buffer: a 974-MB
     # read that sat between the end of backward and AdamW (0.26 ms of the step's serial tail). A bucket's gradients are
@@ -278,7 +283,7 @@ class GradSynchronizer:
     def take_grad_norm_sq(self, out: torch.Tensor) -> bool:
         """After `finish()`: `out[0]` = sum of the bucket partials (this rank's pieces when sharded), in bucket order.
         False when the partials are not kept (CPU tensors): the caller then reads the buffer itself."""
-        if self._norm_parts is None:
+        if self._norm_parts is None or not self.norm_on:
             return False
         if self._norm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._norm_stream)
@@ -319,12 +324,12 @@ class GradSynchronizer:
         if self.active:
             work = self._launch(*self.buckets[b])
             self._works.append(work)
-        if self._norm_parts is not None:
+        if self._norm_parts is not None and self.norm_on:
             self._bucket_norm(b, work)
         self._next += 1
 
     def on_segment_done(self, name: str) -> None:
-        if not self.active and self._norm_parts is None:
+        if not self.active and (self._norm_parts is None or not self.norm_on):
             return
         end = self.segment_end.get(name)
         if end is None:
@@ -334,7 +339,7 @@ class GradSynchronizer:
 
     def finish(self) -> float:
         """Flush remaining buckets, wait for all of them; returns the factor that turns the sum into the mean."""
-        if self.active or self._norm_parts is not None:
+        if self.active or (self._norm_parts is not None and self.norm_on):
             while self._next < len(self.buckets):
                 self._bucket_final()
             for w in self._works:
@@ -451,6 +456,7 @@ class Trainer:
         gas = self.args.gradient_accumulation_steps
         self._micro += 1
         last = self._micro % gas == 0
+        self.sync.norm_on = bool(self.args.bucket_grad_norm)
         hook = self.sync.on_segment_done if last else None
         with model.engine.block("K1-K15 forward + backward"):
             loss = model.forward_backward(inputs, gscale=1.0 / gas, on_segment_done=hook)

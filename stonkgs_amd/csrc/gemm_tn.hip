@@ -22,6 +22,7 @@
 // persistent 256x256 variant (gemm256.hip, TN = true)
 int stonk_gemm256_tn_launch(const stonk_gemm::GemmArgs& a, hipStream_t st);
 int stonk_gemm_tn_w4_launch(const stonk_gemm::GemmArgs& a, hipStream_t st);
+int stonk_gemm_tn_a4_launch(const stonk_gemm::GemmArgs& a, hipStream_t st);
 
 namespace {
 
@@ -201,6 +202,10 @@ extern "C" int stonk_gemm_tn_bf16(const void* dY, int64_t lda, const void* X, in
     STONK_CHECK_ARG(M >= 256 && N >= 256, STONK_ESHAPE);
     // (operands are addressed per 64-token K tile: 64 rows of either operand must stay inside 32-bit byte offsets)
     STONK_CHECK_ARG(lda % 64 == 0 && ldb % 64 == 0 && lda < (1L << 23) && ldb < (1L << 23), STONK_ESHAPE);
+    // (split_k == -2, or <= -2016 = held to -split_k - 2000 CUs: the compiled four-wave kernel, gemm_tn_w4.hip, which the
+    // written-out one replaced in round 4 - kept reachable for A/B runs)
+    const bool old_w4 = split_k == -2 || split_k <= -2016;
+    if (old_w4) split_k = split_k == -2 ? 0 : split_k + 2000;
     STONK_CHECK_ARG(split_k >= -1024, STONK_ESHAPE);
     stonk_gemm::GemmArgs g = {};
     g.A = (const bf16*)dY; g.B = (const bf16*)X; g.C = dW; g.bias = dbias; g.k_dev = k_dev;
@@ -212,6 +217,7 @@ extern "C" int stonk_gemm_tn_bf16(const void* dY, int64_t lda, const void* X, in
     if (sk > nk / 8) sk = nk / 8 > 0 ? nk / 8 : 1;
     g.split_k = (int)sk;
     g.flags = (int)cus;   // grid cap
+    if (split_k != -1 && !old_w4) return stonk_gemm_tn_a4_launch(g, (hipStream_t)stream);
     if (split_k != -1) return stonk_gemm_tn_w4_launch(g, (hipStream_t)stream);
     return stonk_gemm256_tn_launch(g, (hipStream_t)stream);
   }

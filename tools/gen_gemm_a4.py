@@ -197,6 +197,154 @@ def emit(name, lines):
     return f"#define {name} \\\n" + body.replace("\n", " \\\n") + "\n"
 
 
+
+# ===================================================================================== the weight-gradient (TN) form
+# gemm_tn_a4.hip: C[M', N'] += A[T, M']^T . B[T, N'] - the contraction runs over the ROWS (tokens) of both operands. Same
+# pipeline and register map as above (256 x 256 tiles, accumulators a[0:255], fragments v[128:255]); what differs:
+#  * a K tile is 64 token rows x 512 B per operand; a piece (1 KiB) = TWO token rows, so the image is again lane-linear and
+#    every piece reads eight full 128-byte lines; rows are 512 B apart (all rows alias the same banks), so the 32-byte
+#    feature-block segments of a row are XOR-permuted by f(row) = (row & 3) | ((row >> 3) & 1) << 2 - on the source;
+#  * a fragment = two transposed reads (ds_read_b64_tr_b16: 4 token rows x 16 features per 16-lane group, lane i receives
+#    feature i): k group g of the 32-token k-half = tokens 8 g .. 8 g + 7, rows 8 g + {0-3} then 8 g + {4-7}; the half-wave's
+#    eight rows land in eight different 32-byte bank slots. One per-lane address per feature block (the permutation is
+#    per lane), everything else immediates;
+#  * srcA = the A (dY) fragment: D[m][n], a lane holds output column n - what the atomic epilogue wants;
+#  * the bias gradient (column sums of dY): one more MFMA per A block against an all-ones operand into VGPR accumulators
+#    the compiler owns, on every ntn-th K tile (a second copy of each K-tile body, chosen by a scalar branch);
+#  * the cursors carry 64-bit "bytes left" counts (an operand can exceed 4 GB): num_records = clamp(bytes left).
+TN_IMG = 32768
+
+
+def tn_frag_reads(h, stage):
+    r = []
+    for j in range(8):
+        b = 160 + 64 * h + 4 * j
+        off = stage * TN_IMG + h * 16384
+        r.append([f"ds_read_b64_tr_b16 v[{b}:{b + 1}], %[taB{j}] offset:{off}",
+                  f"ds_read_b64_tr_b16 v[{b + 2}:{b + 3}], %[taB{j}] offset:{off + 2048}"])
+    for i in range(8):
+        b = 128 + 64 * h + 4 * i
+        off = stage * TN_IMG + h * 16384
+        r.append([f"ds_read_b64_tr_b16 v[{b}:{b + 1}], %[taA{i}] offset:{off}",
+                  f"ds_read_b64_tr_b16 v[{b + 2}:{b + 3}], %[taA{i}] offset:{off + 2048}"])
+    return r
+
+
+def tn_clamp(rlo, rhi, nrec):
+    return [f"s_cmp_lt_i32 {rhi}, 0", f"s_cselect_b32 s48, 0, {rlo}", f"s_cmp_gt_i32 {rhi}, 0",
+            f"s_cselect_b32 s48, 0xfffff000, s48", f"s_min_u32 {nrec}, s48, 0xfffff000"]
+
+
+TN_ADVANCE_A = ["s_add_u32 s36, s36, %[stepa]", "s_addc_u32 s37, s37, 0", "s_sub_u32 %[ralo], %[ralo], %[stepa]",
+                "s_subb_u32 %[rahi], %[rahi], 0"] + tn_clamp("%[ralo]", "%[rahi]", "s38")
+TN_ADVANCE_B = ["s_add_u32 s40, s40, %[stepb]", "s_addc_u32 s41, s41, 0", "s_sub_u32 %[rblo], %[rblo], %[stepb]",
+                "s_subb_u32 %[rbhi], %[rbhi], 0"] + tn_clamp("%[rblo]", "%[rbhi]", "s42")
+# the last pair of K tiles of a work item prefetches the NEXT item's first two: cursor := the next item's
+TN_SWITCH = (["s_cmp_eq_u32 %[rem], 1", "s_cbranch_scc0 L_tn_nosw_{u}_%=",
+              "s_mov_b32 s36, %[nal]", "s_mov_b32 s37, %[nah]", "s_mov_b32 %[ralo], %[nralo]", "s_mov_b32 %[rahi], %[nrahi]",
+              "s_mov_b32 s40, %[nbl]", "s_mov_b32 s41, %[nbh]", "s_mov_b32 %[rblo], %[nrblo]", "s_mov_b32 %[rbhi], %[nrbhi]"]
+             + tn_clamp("%[ralo]", "%[rahi]", "s38") + tn_clamp("%[rblo]", "%[rbhi]", "s42") + ["L_tn_nosw_{u}_%=:"])
+
+
+def tn_ktile(c, stage, first, sched, duty):
+    nm = 64
+    side = [[] for _ in range(2 * nm)]
+    busy = [False] * (2 * nm)
+
+    def place(g, ins):
+        while busy[g]:
+            g += 1
+        busy[g] = True
+        side[g] += ins if isinstance(ins, list) else [ins]
+        return g
+
+    g = sched["read1_start"]
+    last_read = g
+    for ins in tn_frag_reads(1, stage):
+        last_read = place(g, ins)
+        g += sched["read_step"]
+    b1 = sched["b1_gap"]
+    assert last_read < b1
+    side[b1] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    b2 = nm + sched["b2_gap"]
+    g = b2 + 1
+    for ins in tn_frag_reads(0, stage ^ 1):
+        last_read = place(g, ins)
+        g += sched.get("read2_step", sched["read_step"])
+    assert last_read <= 2 * nm - 2, (last_read, 2 * nm)
+    side[2 * nm - 2].append("s_waitcnt lgkmcnt(0)")
+    ops = dma_ops(c, stage)
+    g = b1 + 2
+    m0_gap = b1 + 1
+    last_dma = b1
+    for m0, ld in ops:
+        side[m0_gap].append(m0)
+        at = place(max(g, m0_gap + 1), ld)
+        m0_gap = at + 1
+        last_dma = at
+        g = at + sched["dma_step"]
+    assert last_dma + 3 < 2 * nm, last_dma
+    side[last_dma + 1] += TN_ADVANCE_A
+    side[last_dma + 2] += TN_ADVANCE_B
+    issued = sum(1 for gg in range(b2) for ins in side[gg] if ins.startswith("buffer_load"))
+    side[b2].insert(0, f"s_waitcnt vmcnt({issued})")
+    side[b2].insert(1, "s_barrier")
+    out = []
+    n = 0
+    for h in range(2):
+        for i in range(8):
+            for j in range(8):
+                fa_, fb_ = fa(h, i), fb(h, j)
+                cc = "0" if (first and h == 0) else acc(c, i, j)
+                out.append(f"v_mfma_f32_16x16x32_bf16 {acc(c, i, j)}, {fa_}, {fb_}, {cc}")
+                out.extend(side[n])
+                n += 1
+            if duty:   # column sums of dY: A fragment x ones, into the compiler's VGPR accumulators
+                out.append(f"v_mfma_f32_16x16x32_bf16 %[bacc{i}], {fa(h, i)}, %[ones], %[bacc{i}]")
+    return out
+
+
+def tn_position(c, stage, first, sched, uid):
+    """One K tile, in its two forms, and the bias-duty bookkeeping around them."""
+    t = ["s_cmp_eq_u32 %[bph], 0", f"s_cbranch_scc1 L_tn_duty_{uid}_%="]
+    t += tn_ktile(c, stage, first, sched, False)
+    t += [f"s_branch L_tn_join_{uid}_%=", f"L_tn_duty_{uid}_%=:"]
+    t += tn_ktile(c, stage, first, sched, True)
+    t += [f"L_tn_join_{uid}_%=:", "s_add_u32 %[bph], %[bph], 1", "s_cmp_eq_u32 %[bph], %[ntn]", "s_cselect_b32 %[bph], 0, %[bph]"]
+    return t
+
+
+def tn_tile_asm(c, sched):
+    t = []
+    for ins in tn_frag_reads(0, 0):
+        t += ins
+    t += [x.replace("{u}", "a") for x in TN_SWITCH]
+    t.append("s_waitcnt lgkmcnt(0)")
+    t += tn_position(c, 0, True, sched, "p0")
+    t += tn_position(c, 1, False, sched, "p1")
+    t += ["s_sub_u32 %[rem], %[rem], 1", "s_cmp_eq_u32 %[rem], 0", "s_cbranch_scc1 L_tn_end_%="]
+    t.append("L_tn_loop_%=:")
+    t += [x.replace("{u}", "b") for x in TN_SWITCH]
+    t += tn_position(c, 0, False, sched, "l0")
+    t += tn_position(c, 1, False, sched, "l1")
+    t += ["s_sub_u32 %[rem], %[rem], 1", "s_cmp_lg_u32 %[rem], 0", "s_cbranch_scc1 L_tn_loop_%="]
+    t.append("L_tn_end_%=:")
+    t += ["s_nop 7", "s_nop 7"]
+    return t
+
+
+def tn_prologue_asm(c):
+    t = []
+    for stage in range(2):
+        for m0, ld in dma_ops(c, stage):
+            t += [m0, "s_nop 0", ld]
+        t += TN_ADVANCE_A + TN_ADVANCE_B
+    t += [f"s_waitcnt vmcnt({c.ndma})", "s_barrier"]
+    return t
+
+
+TN_SCHED = {"read1_start": 1, "read_step": 1, "b1_gap": 20, "dma_step": 6, "b2_gap": 30}
+
 # Where the side instructions sit (gap = after that MFMA of the K tile). Chosen on MI355X by tools/a4_sweep.py (round 4,
 # profiles/r04_a4_sweep.md): an LDS-DMA issue is the expensive instruction of this loop (8192^3: 587 us with neither reads nor
 # DMA, 619 with the reads, 820 with the DMA one gap in three, 750 one gap in six) - so the pieces are spread as far apart
@@ -219,6 +367,15 @@ def generate(path, overrides=None):
         sched.update((overrides or {}).get(nbj, {}))
         parts.append(emit(f"STONK_A4_PROLOGUE_{c.tag}", prologue_asm(c)))
         parts.append(emit(f"STONK_A4_TILE_{c.tag}", tile_asm(c, sched)))
+    c = Cfg(8)
+    tn_sched = dict(TN_SCHED)
+    tn_sched.update((overrides or {}).get("tn", {}))
+    parts.append("// ---- weight-gradient form (gemm_tn_a4.hip): %[taA0..7] %[taB0..7] transposed-read addresses per feature block,\n"
+                 "// %[ralo/rahi/rblo/rbhi] bytes left in the operands from the cursors, %[stepa/stepb] bytes per K tile,\n"
+                 "// %[nal/nah/nralo/nrahi/nbl/nbh/nrblo/nrbhi] the next work item's cursors, %[bph] / %[ntn] bias duty phase,\n"
+                 "// %[bacc0..7] bias accumulators, %[ones] the all-ones operand; s48 scratch.\n")
+    parts.append(emit("STONK_TN_A4_PROLOGUE", tn_prologue_asm(c)))
+    parts.append(emit("STONK_TN_A4_TILE", tn_tile_asm(c, tn_sched)))
     text = "\n".join(parts)
     if path is None:
         return text

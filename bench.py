@@ -25,15 +25,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM-side bytes per launch of the dominant kernel, from separate rocprofv3 --pmc passes over this command:
-# gemm_tn_w4_kernel (12L/768, average of its 47 launches per step on the unpadded rows): 239.8 MB fetched (FETCH_SIZE
-# doubled, the gfx950 correction of MI355X_MICROARCH.md) + 58.4 MB of float atomics written (profiles/r03_pmc_traffic.csv;
-# algorithmic: 193.5 MB; round 2, 50 launches on padded rows: 283.9 + 57.2)
-TRAFFIC_BYTES = {("150k", "tn_w4"): 301.3e6}
+# gemm_tn_a4_kernel (12L/768, average of its 46 launches per step on the unpadded rows): FETCH_SIZE doubled (the gfx950
+# correction of MI355X_MICROARCH.md) + WRITE_SIZE (float atomics), profiles/r04_pmc_traffic.csv; algorithmic: 193.5 MB.
+# (round 3, gemm_tn_w4_kernel: 242.7 + 58.6 = 301.3 MB)
+TRAFFIC_BYTES = {("150k", "tn_a4"): None}
 KERNEL_NOTES = {
-    "tn_w4": "gemm_tn_w4_kernel (weight + bias gradients: bf16 MFMA 32x32x16, 256x256 tiles over 64-token steps, four waves, "
-             "transposed LDS reads, split-K fp32 atomics)",
+    "tn_a4": "gemm_tn_a4_kernel (weight + bias gradients: bf16 MFMA 16x16x32, 256x256 tiles over 64-token steps, four waves, "
+             "LDS-DMA operands, transposed LDS reads, a written-out K loop, split-K fp32 buffer atomics)",
     "tn": "gemm_tn_kernel (weight + bias gradients on 128x128 tiles)",
-    "nt": "NT forward / dgrad GEMMs (gemm_w4_kernel, gemm256_kernel, gemm_nt_kernel)",
+    "nt": "NT forward / dgrad GEMMs (gemm_a4_kernel - written-out four-wave loop -, gemm256_kernel, gemm_nt_kernel)",
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
 # algorithmic GFLOP per text-triple pair, 12L/768/S=512, label-sparse decoders

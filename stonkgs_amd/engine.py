@@ -46,7 +46,7 @@ class GemmTimer:
 
     def summarize(self, kind=None):
         """Algorithmic FLOPs use the rows / contraction length that exist at run time (device-side counts of the
-        label-sparse decoders), not the launch capacity. kind: "tn_w4" / "tn" (weight-gradient kernels: four-wave 256x256 /
+        label-sparse decoders), not the launch capacity. kind: "tn_a4" / "tn" (weight-gradient kernels: four-wave 256x256, written-out loop /
         128x128), "nt", or None = all."""
         torch.cuda.synchronize()
         tot_t = tot_f = 0.0
@@ -296,7 +296,7 @@ class Engine:
                      dW.stride(0), hip.ptr(db), M_out, N_in, T, alpha, split, hip.ptr(k_dev), hip.stream_ptr())
             if timed:
                 e1.record()
-                self.gemm_timer.records.append(("tn_w4" if split <= 0 else "tn", e0, e1, M_out, N_in, T, None, k_dev))
+                self.gemm_timer.records.append(("tn_a4" if split <= 0 else "tn", e0, e1, M_out, N_in, T, None, k_dev))
 
     def transpose(self, x, rows, cols, name, colsum=None, rows_dev=None):
         rpad = (rows + 63) // 64 * 64

@@ -138,6 +138,7 @@ class Engine:
         # stream after the last parameter write - called before the first trainable weight is read and by every accessor.
         self._opt_stream: Optional[torch.cuda.Stream] = None
         self._params_ready: Optional[torch.cuda.Event] = None
+        self._wt_ready: Optional[torch.cuda.Event] = None   # W^T copies refreshed behind the parameters (refresh_wt_deferred)
         # tools/step_marks.py: a list to collect (name, host time, event on the current stream, was the optimizer's
         # "parameters final" event already complete) at a few points of the step; None (default) = nothing is recorded
         self.marks: Optional[list] = None
@@ -319,12 +320,37 @@ class Engine:
         return (self.seed_base * 0x9E3779B1 + layer * 64 + site) & 0xFFFFFFFF
 
     # ------------------------------------------------------------------ derived weights
-    def refresh_derived(self, bf16_mirror: bool = True) -> None:
-        """bf16 mirrors (if the optimizer has not just written them) and W^T copies for dgrad."""
+    def refresh_derived(self, bf16_mirror: bool = True, transposes: bool = True) -> None:
+        """bf16 mirrors (if the optimizer has not just written them) and W^T copies for dgrad. `transposes=False`: the caller
+        refreshes the W^T copies itself, later (`refresh_wt_deferred`)."""
         st = hip.stream_ptr()
         if bf16_mirror:
             for s in (self.P, self.BB):
                 hip.call("stonk_cast_f32_to_bf16", s.data.data_ptr(), s.bf16.data_ptr(), s.numel, st)
+        if transposes:
+            self.wait_wt()   # (a deferred refresh still in flight writes the same copies)
+            self._refresh_wt(st)
+
+    def refresh_wt_deferred(self) -> None:
+        """The W^T copies BEHIND the "parameters final" event (round 4): only backward's dgrad launches read them, ten
+        milliseconds into the next step, so the 0.2-ms transpose of 0.49 GB runs on the optimizer stream beside the next
+        step's forward instead of between AdamW and it; `backward` waits for `_wt_ready`."""
+        stream = self._opt_stream if self._opt_stream is not None and self._params_ready is not None else None
+        if stream is None:
+            self._refresh_wt(hip.stream_ptr())
+            return
+        with torch.cuda.stream(stream):
+            self._refresh_wt(hip.stream_ptr())
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        self._wt_ready = ev
+
+    def wait_wt(self) -> None:
+        ev = self._wt_ready
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def _refresh_wt(self, st) -> None:
         if self._wt_desc is None or self._wt_desc[3] != self.P.bf16.data_ptr():   # (the table holds raw addresses)
             self._wt_desc = self._build_wt_table()
         desc, n, tiles, _ = self._wt_desc
@@ -841,6 +867,7 @@ class Engine:
         if sv is None:
             raise RuntimeError("backward() without a training forward (labels are required)")
         self.saved = None
+        self.wait_wt()
         cfg = self.cfg
         H, S, half = cfg.hidden_size, cfg.max_position_embeddings, cfg.half_length
         B = sv["B"]
@@ -1027,6 +1054,7 @@ class Engine:
         if sv is None:
             raise RuntimeError("backward_cls() without a training forward (labels are required)")
         self.saved = None
+        self.wait_wt()
         cfg = self.cfg
         H, S = cfg.hidden_size, cfg.max_position_embeddings
         B, C = sv["B"], sv["num_labels"]

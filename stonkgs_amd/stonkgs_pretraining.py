@@ -69,6 +69,10 @@ class TrainingArguments:
     # ABI's own communicator (stonk_comm_*: RCCL on a library-owned stream with event hand-off; torch.distributed, if
     # initialised, only carries the 128-byte RCCL id once)
     comm_backend: str = "torch"
+    # refresh the bf16 W^T copies (read by backward's dgrad launches only) behind the "parameters final" event, beside the
+    # next step's forward, instead of in front of it. OFF: measured (round 4, tools/ab_step.py args:defer_wt_refresh) 27.22
+    # against 27.16 ms - the 0.2-ms transpose is then paid beside the forward's first GEMMs instead of before them
+    defer_wt_refresh: bool = False
 
 
 def linear_schedule_lr(base_lr: float, step: int, max_steps: int, warmup: int = 0) -> float:
@@ -473,7 +477,10 @@ class Trainer:
                 if self.sync.shard:
                     model._store.grad.zero_()               # (the kernel zeroed the owned pieces only)
                     self.sync.gather_params(model._store.data)
-                model.engine.refresh_derived(bf16_mirror=self.sync.shard)   # sharded: the bf16 mirror of the gathered pieces too
+                # sharded: the bf16 mirror of the gathered pieces too; the W^T copies follow behind "parameters final"
+                model.engine.refresh_derived(bf16_mirror=self.sync.shard, transposes=not self.args.defer_wt_refresh)
+            if self.args.defer_wt_refresh:
+                model.engine.refresh_wt_deferred()
             self.global_step += 1
         return loss
 

@@ -29,7 +29,7 @@ for rnd in range(5):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(10):
-            tr.training_step(model, batches[i % 4])
+            tr.training_step(model, batches[i % 4], next_inputs=batches[(i + 1) % 4])
         torch.cuda.synchronize()
         res[v].append((time.perf_counter() - t0) / 10 * 1e3)
 for v in values:

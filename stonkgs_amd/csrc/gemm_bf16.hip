@@ -427,4 +427,4 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   }
 }
 
-extern "C" int stonk_abi_version(void) { return 3; }
+extern "C" int stonk_abi_version(void) { return 4; }   // 4: stonk_comm_*, STONK_GEMM_ASM4*, written-out TN kernel behind split_k <= 0

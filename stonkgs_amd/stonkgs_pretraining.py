@@ -45,6 +45,10 @@ class TrainingArguments:
     save_total_limit: int = 5
     seed: int = 42
     ddp_bucket_mb: float = 64.0
+    # the last `ddp_tail_mb` of the gradient buffer (what backward finishes last) in buckets of >= `ddp_tail_bucket_mb`: the
+    # final bucket's collective is exposed in full, so it should be small (one encoder layer = 28 MB fp32)
+    ddp_tail_mb: float = 100.0
+    ddp_tail_bucket_mb: float = 24.0
     # clip + AdamW + W^T refresh (and the tail of the gradient all-reduce) on their own stream, beside the next step's
     # frozen-backbone forward; parameters read through the model's accessors or after torch.cuda.synchronize() are final
     optimizer_overlap: bool = True
@@ -189,16 +193,26 @@ class FusedAdamW:
                 dst[soff:soff + n].copy_(src[off:off + n])
 
 
-def plan_buckets(segment_ends: List[int], bucket_elems: int) -> List[tuple]:
+def plan_buckets(segment_ends: List[int], bucket_elems: int, tail_elems: int = 0, tail_bucket_elems: int = 0) -> List[tuple]:
     """Cut the flat gradient buffer into contiguous [lo, hi) buckets whose boundaries are segment ends (a segment =
-    what one backward notification finalises), each at least `bucket_elems` long except possibly the last."""
+    what one backward notification finalises), each at least `bucket_elems` long except possibly the last.
+
+    `tail_elems` / `tail_bucket_elems` (round 4, from tools/overlap_budget.py's timeline): the last `tail_elems` elements of
+    the buffer - what backward finishes LAST - are cut into buckets of at least `tail_bucket_elems` instead. The collective
+    of the final bucket cannot start before backward ends, so its duration is exposed whatever the bandwidth: with uniform
+    64 MB buckets that was an 85 MB bucket (the last three layers), with a tapered tail it is one layer."""
     buckets, lo = [], 0
+    total = segment_ends[-1] if segment_ends else 0
     for end in segment_ends:
-        if end - lo >= bucket_elems:
+        want = tail_bucket_elems if (tail_bucket_elems and total - end < tail_elems) else bucket_elems
+        if end - lo >= want:
             buckets.append((lo, end))
             lo = end
-    if segment_ends and lo < segment_ends[-1]:
-        buckets.append((lo, segment_ends[-1]))
+    if segment_ends and lo < total:
+        if buckets and tail_bucket_elems and total - lo < tail_bucket_elems // 4:   # (a sliver: the embeddings' few tensors)
+            buckets[-1] = (buckets[-1][0], total)
+        else:
+            buckets.append((lo, total))
     return buckets
 
 
@@ -220,7 +234,7 @@ class GradSynchronizer:
     that divides 64 cuts them into 16-byte aligned pieces."""
 
     def __init__(self, grad: torch.Tensor, segments: Dict[str, int], bucket_mb: float = 64.0, group=None,
-                 force: bool = False, shard: bool = False, comm=None):
+                 force: bool = False, shard: bool = False, comm=None, tail_mb: float = 0.0, tail_bucket_mb: float = 0.0):
         """`force`: issue the collectives even in a one-rank group (a sum over one rank: the values do not change) - lets
         a one-GPU box execute the RCCL path, its stream ordering and the kernel routing that goes with it."""
         import torch.distributed as dist
@@ -240,7 +254,8 @@ class GradSynchronizer:
             self.active = self.world > 1 or (force and dist.is_initialized())
         self.segment_end = dict(segments)  # notification name -> end offset in the flat buffer
         ends = sorted(set(segments.values()))
-        self.buckets = plan_buckets(ends, int(bucket_mb * (1 << 20) / 4))
+        self.buckets = plan_buckets(ends, int(bucket_mb * (1 << 20) / 4), int(tail_mb * (1 << 20) / 4),
+                                    int(tail_bucket_mb * (1 << 20) / 4))
         self.shard = bool(shard) and self.active
         if self.shard:
             bad = [(lo, hi) for lo, hi in self.buckets if (hi - lo) % (4 * self.world)]
@@ -421,7 +436,8 @@ class Trainer:
             raise ValueError("comm_backend must be 'torch' or 'stonk'")
         self.comm = comm
         self.sync = GradSynchronizer(model._store.grad, segment_ends_for(model), self.args.ddp_bucket_mb,
-                                     force=self.args.ddp_force_collectives, shard=self.args.shard_optimizer, comm=comm)
+                                     force=self.args.ddp_force_collectives, shard=self.args.shard_optimizer, comm=comm,
+                                     tail_mb=self.args.ddp_tail_mb, tail_bucket_mb=self.args.ddp_tail_bucket_mb)
         self.optimizer = FusedAdamW(model._store, (self.args.adam_beta1, self.args.adam_beta2), self.args.adam_epsilon,
                                     self.args.weight_decay, self.args.max_grad_norm, spans=self.sync.owned_spans())
         model.engine.comm_overlap = self.sync.active   # (see Engine.comm_overlap)

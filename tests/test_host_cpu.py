@@ -89,6 +89,12 @@ def test_plan_buckets_covers_buffer_exactly():
     assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
     assert all(hi in ends for _, hi in b)
     assert plan_buckets([10], 100) == [(0, 10)] and plan_buckets([], 10) == []
+    # tapered tail: the last 300 elements in buckets of >= 100 - the final bucket (exposed in full) is small; a sliver joins
+    # its predecessor; everything before the tail keeps the large buckets
+    ends = [400, 800, 900, 1000, 1100, 1200, 1210]
+    t = plan_buckets(ends, 400, tail_elems=320, tail_bucket_elems=100)
+    assert t == [(0, 400), (400, 800), (800, 900), (900, 1000), (1000, 1100), (1100, 1210)], t
+    assert plan_buckets(ends, 400) == [(0, 400), (400, 800), (800, 1200), (1200, 1210)]
 
 
 def test_library_exports_every_declared_symbol():
@@ -99,7 +105,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _hip.lib().stonk_abi_version() == 3
+    assert _hip.lib().stonk_abi_version() == 4
     assert _hip.lib().stonk_sumsq_workspace_floats() == 1025
     assert _hip.lib().stonk_layernorm_bwd_workspace_floats(32768, 768) == 1024 * 2 * 768   # (no GPU touched: a size query)
     assert _hip.lib().stonk_layernorm_bwd_workspace_floats(0, 768) == 0

@@ -32,70 +32,71 @@ def main():
     batches = [{k: v.to(dev) for k, v in synthetic_batch(64, cfg.vocab_size, cfg.kg_vocab_size, 512, seed=1234 + i).items()}
                for i in range(4)]
     sync = tr.sync
-    buckets = sync.buckets
+    from stonkgs_amd.stonkgs_pretraining import plan_buckets
     rec = {}
 
     def hook(name):   # runs under the weight-gradient stream, behind the segment's last weight-gradient GEMM
         end = sync.segment_end.get(name)
         if end is None:
             return
-        while rec["next"] < len(buckets) and buckets[rec["next"]][1] <= end:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            rec["final"].append(ev)
-            rec["next"] += 1
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        rec[end] = ev
 
     for i in range(6):
         tr.training_step(model, batches[i % 4], next_inputs=batches[(i + 1) % 4])
     torch.cuda.synchronize()
     runs = []
     for i in range(6):
-        rec.update(next=0, final=[])
+        rec.clear()
         model.engine.marks = []
         inputs = tr._on_device(batches[i % 4])
         model.train()
-        t0 = torch.cuda.Event(enable_timing=True)
-        loss = model.forward_backward(inputs, gscale=1.0, on_segment_done=hook)
+        model.forward_backward(inputs, gscale=1.0, on_segment_done=hook)
         t_end = torch.cuda.Event(enable_timing=True)
         t_end.record()                     # main stream: backward done AND joined with the weight-gradient stream
         marks, model.engine.marks = model.engine.marks, None
         torch.cuda.synchronize()
-        bwd_begin = next(m[2] for m in marks if m[0] == "encoder_fwd_begin")
+        begin = next(m[2] for m in marks if m[0] == "encoder_fwd_begin")
         model._store.grad.zero_()
-        while rec["next"] < len(buckets):  # (a tail bucket that no notification closes is final at the end of backward)
-            rec["final"].append(t_end)
-            rec["next"] += 1
-        runs.append(([bwd_begin.elapsed_time(e) for e in rec["final"]], bwd_begin.elapsed_time(t_end)))
-    # median over the runs, bucket by bucket
-    nb = len(buckets)
-    final = [sorted(r[0][b] for r in runs)[len(runs) // 2] for b in range(nb)]
+        runs.append(({end: begin.elapsed_time(e) for end, e in rec.items()}, begin.elapsed_time(t_end)))
+    ends = sorted(set(sync.segment_end.values()))
+    seg_final = {e: sorted(r[0].get(e, r[1]) for r in runs)[len(runs) // 2] for e in ends}   # (never notified: end of backward)
     t_end = sorted(r[1] for r in runs)[len(runs) // 2]
+    mb = lambda n: int(n * (1 << 20) / 4)   # noqa: E731
+    plans = [("uniform 64 MB buckets (rounds 2-3)", plan_buckets(ends, mb(64))),
+             ("64 MB buckets, the last 100 MB in >= 24 MB buckets (default since round 4)", plan_buckets(ends, mb(64), mb(100), mb(24)))]
     lines = ["# Gradient-exchange budget from one GPU's timeline (round 4, tools/overlap_budget.py)", "",
              f"BASELINE config 2, per-GPU batch 64. Times in ms from the first encoder launch of the step; forward + heads + "
              f"backward end at **{t_end:.2f} ms** (weight-gradient stream joined). A bucket = a contiguous slice of the flat fp32 "
-             "gradient buffer, all-reduced when backward reports it final.", "",
-             "| bucket | elements | fp32 MB | final at (ms) | time left until backward ends (ms) |", "|---|---|---|---|---|"]
-    for b, (lo, hi) in enumerate(buckets):
-        lines.append(f"| {b} | {hi - lo:,} | {(hi - lo) * 4 / 1e6:.1f} | {final[b]:.2f} | {t_end - final[b]:.2f} |")
-    total = sum(hi - lo for lo, hi in buckets)
-    lines += ["", f"Total {total:,} elements = {total * 4 / 1e6:.0f} MB fp32 / {total * 2 / 1e6:.0f} MB bf16 per step and GPU.", "",
-              "## Predicted exposed communication (ring model, see the tool's header)", "",
-              "`exposed` = time the optimizer would wait for the last bucket after backward has ended; 20 us latency per collective.", "",
-              "| N | payload | bus bandwidth (GB/s) | ring time, all buckets (ms) | exposed (ms) | step stretch at 27.0 ms |", "|---|---|---|---|---|---|"]
-    for N in (2, 4, 8):
-        for payload, bpe in (("fp32", 4), ("bf16", 2)):
-            for bw in (100, 200, 300, 400):
-                t, tot = 0.0, 0.0
-                for b, (lo, hi) in enumerate(buckets):
-                    dur = 2 * (N - 1) / N * (hi - lo) * bpe / (bw * 1e9) * 1e3 + 0.02
-                    t = max(t, final[b]) + dur
-                    tot += dur
-                exposed = max(0.0, t - t_end)
-                lines.append(f"| {N} | {payload} | {bw} | {tot:.2f} | {exposed:.2f} | {exposed / 27.0 * 100:.1f} % |")
-    lines += ["", "Reading: the entity decoder's gradient (55 % of the bytes) is final first, within the first milliseconds of "
-              "backward, and the encoder's buckets follow at one per one-to-two layers; what can be exposed is the tail - the last "
-              "bucket (embeddings / first layers), final only when backward ends, plus whatever queue the earlier buckets have left "
-              "on the communication stream. With fp32 payloads the tail alone is a few MB; the queue is what the bus bandwidth decides."]
+             "gradient buffer, all-reduced when backward reports it final (an event on the weight-gradient stream, where the "
+             "collective is issued).", ""]
+    for title, buckets in plans:
+        final = [seg_final[hi] for lo, hi in buckets]
+        lines += [f"## {title}", "", "| bucket | elements | fp32 MB | final at (ms) | time left until backward ends (ms) |", "|---|---|---|---|---|"]
+        for b, (lo, hi) in enumerate(buckets):
+            lines.append(f"| {b} | {hi - lo:,} | {(hi - lo) * 4 / 1e6:.1f} | {final[b]:.2f} | {t_end - final[b]:.2f} |")
+        total = sum(hi - lo for lo, hi in buckets)
+        lines += ["", f"Total {total:,} elements = {total * 4 / 1e6:.0f} MB fp32 / {total * 2 / 1e6:.0f} MB bf16 per step and GPU.", "",
+                  "Predicted exposed communication (ring model, see the tool's header): `exposed` = time the optimizer would wait for "
+                  "the last bucket after backward has ended; 20 us latency per collective.", "",
+                  "| N | payload | bus bandwidth (GB/s) | ring time, all buckets (ms) | exposed (ms) | step stretch at 27.0 ms |", "|---|---|---|---|---|---|"]
+        for N in (2, 4, 8):
+            for payload, bpe in (("fp32", 4), ("bf16", 2)):
+                for bw in (100, 200, 300, 400):
+                    t, tot = 0.0, 0.0
+                    for b, (lo, hi) in enumerate(buckets):
+                        dur = 2 * (N - 1) / N * (hi - lo) * bpe / (bw * 1e9) * 1e3 + 0.02
+                        t = max(t, final[b]) + dur
+                        tot += dur
+                    exposed = max(0.0, t - t_end)
+                    lines.append(f"| {N} | {payload} | {bw} | {tot:.2f} | {exposed:.2f} | {exposed / 27.0 * 100:.1f} % |")
+        lines.append("")
+    lines += ["Reading: the entity decoder's gradient (55 % of the bytes) is final when backward has barely begun and has all of "
+              "backward to travel; the encoder's buckets follow at one per three layers. What is exposed is the LAST bucket - final "
+              "only when backward ends - plus whatever queue the earlier ones have left: with uniform buckets that last bucket is "
+              "85 MB (three layers), with the tapered tail one layer (28 MB). Above ~200 GB/s of bus bandwidth the exposed time is the "
+              "last bucket's own ring time and nothing else; fp32 against bf16 payloads then differ by that bucket's half."]
     out = "\n".join(lines) + "\n"
     print(out)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r04_overlap_budget.md")

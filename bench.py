@@ -131,7 +131,7 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(cfg, seconds_budget=60.0):
+def cpu_baseline(cfg, seconds_budget=72.0):
     """The oracle (CPU restatement of the reference's HuggingFace path, pinned by tests/test_oracle_golden.py) timed
     on this host's cores: full training steps at the SAME model shape on a bounded sample - batch 8 as SURVEY section 8d
     specifies, at all the threads this process may use and, as a second point, at 8 threads."""
@@ -162,10 +162,10 @@ def cpu_baseline(cfg, seconds_budget=60.0):
             log(f"cpu_baseline[{threads} threads]: step {n} at {time.time() - t0:.1f} s")
         return n, time.time() - t0
 
-    n, dt = timed(cores, seconds_budget * 0.55, 5, 2)
+    n, dt = timed(cores, seconds_budget * 0.55, 5, 3)   # three warm-up steps, five timed
     out = {"value": B * n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
            "sample": f"{n} full fp32 training steps (forward, backward, clip, AdamW) of the CPU oracle at the same model "
-                     f"shape, batch {B} (seq 512, V={ocfg.vocab_size}, K={ocfg.kg_vocab_size}), after two warm-up steps; "
+                     f"shape, batch {B} (seq 512, V={ocfg.vocab_size}, K={ocfg.kg_vocab_size}), after three warm-up steps; "
                      f"torch {torch.__version__}, mkldnn {torch.backends.mkldnn.is_available()}, "
                      f"mkl {torch.backends.mkl.is_available()}"}
     if cores > 8:

@@ -15,11 +15,14 @@ SW = os.path.join(ROOT, "ab_ref", "sweep")   # (build/ does not travel to the GP
 
 VARIANTS = {
     "v0_base": {},
-    "v9_dma6": {8: dict(b1_gap=20, dma_step=6, b2_gap=30), 6: dict(b1_gap=18, dma_step=4, b2_gap=30)},
-    "a3_base_linsrc": {"defs": ["-DSTONK_A4_LINEAR_SRC"]},
-    "a4_dma6_linsrc": {8: dict(b1_gap=20, dma_step=6, b2_gap=30), 6: dict(b1_gap=18, dma_step=4, b2_gap=30), "defs": ["-DSTONK_A4_LINEAR_SRC"]},
-    "a0_nodma": {8: dict(ablate=("dma",)), 6: dict(ablate=("dma",))},
-    "a2_mfma_only": {8: dict(ablate=("dma", "reads")), 6: dict(ablate=("dma", "reads"))},
+    "n1_b1_18": {8: dict(b1_gap=18, dma_step=6, b2_gap=30)},
+    "n2_b2_40": {8: dict(b1_gap=20, dma_step=6, b2_gap=40), 6: dict(b1_gap=18, dma_step=4, b2_gap=36)},
+    "n3_192_dma5": {6: dict(b1_gap=16, dma_step=5, b2_gap=28)},
+    "t1_dma5": {"tn": dict(dma_step=5)},
+    "t2_dma4": {"tn": dict(dma_step=4)},
+    "t3_b2_40": {"tn": dict(b2_gap=40)},
+    "t4_b2_20": {"tn": dict(b2_gap=20)},
+    "t5_b1_18": {"tn": dict(b1_gap=18)},
 }
 
 
@@ -27,7 +30,7 @@ def build():
     import gen_gemm_a4 as gen
     os.makedirs(SW, exist_ok=True)
     csrc = os.path.join(ROOT, "stonkgs_amd", "csrc")
-    others = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".o") and f != "gemm_a4.o"]
+    others = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".o") and f not in ("gemm_a4.o", "gemm_tn_a4.o")]
     procs = []
     for name, ov in VARIANTS.items():
         inc = os.path.join(SW, name + ".inc")
@@ -36,18 +39,25 @@ def build():
         except (AssertionError, IndexError) as e:
             print(name, "schedule does not fit:", e)
             continue
-        obj = os.path.join(SW, name + ".o")
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
-               "-Wno-unused-result", "-Wno-inline-asm", "-ffp-contract=fast", f'-DSTONK_A4_LOOP_INC="{inc}"'] + ov.get("defs", []) + ["-c",
-               os.path.join(csrc, "gemm_a4.hip"), "-o", obj]
-        procs.append((name, obj, subprocess.Popen(cmd)))
-        if len(procs) % 4 == 0:
-            for _, _, p in procs[-4:]:
-                p.wait()
-    for name, obj, p in procs:
+        objs = []
+        for src in ("gemm_a4", "gemm_tn_a4"):
+            obj = os.path.join(SW, f"{name}_{src}.o")
+            objs.append(obj)
+            cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+                   "-Wno-unused-result", "-Wno-inline-asm", "-ffp-contract=fast", f'-DSTONK_A4_LOOP_INC="{inc}"'] + ov.get("defs", []) + ["-c",
+                   os.path.join(csrc, src + ".hip"), "-o", obj]
+            procs.append((name, subprocess.Popen(cmd)))
+            if len(procs) % 6 == 0:
+                for _, p in procs[-6:]:
+                    p.wait()
+        VARIANTS[name]["_objs"] = objs
+    for name, p in procs:
         assert p.wait() == 0, name
+    for name, ov in VARIANTS.items():
+        if "_objs" not in ov:
+            continue
         so = os.path.join(SW, f"libstonk_{name}.so")
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, obj] + others)
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + ov["_objs"] + others + ["-ldl"])
         print("built", os.path.relpath(so, ROOT))
 
 
@@ -96,6 +106,33 @@ def run():
                 torch.cuda.synchronize()
                 res[k].append(e0.elapsed_time(e1) / 10 * 1e3)
         print(f"{sname} {M}x{N}x{K} kernel {kern}: " + "  ".join(f"{k} {statistics.median(v):.1f}" for k, v in res.items()), flush=True)
+    # the weight gradient (gemm_tn_a4.hip), held to 160 CUs' worth of workgroups as the step launches it
+    for sname, Mo, No in (("tn_ffn_up", 3072, 768), ("tn_ffn_down", 768, 3072), ("tn_qkv", 2304, 768)):
+        g = torch.Generator(device="cuda").manual_seed(2)
+        dY = (torch.randn(T, Mo, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+        X = (torch.randn(T, No, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+        dW = torch.zeros(Mo, No, device="cuda")
+        db = torch.zeros(Mo, device="cuda")
+
+        def call_tn(lib):
+            rc = lib.stonk_gemm_tn_bf16(vp(dY.data_ptr()), i64(Mo), vp(X.data_ptr()), i64(No), vp(dW.data_ptr()), i64(No), vp(db.data_ptr()),
+                                        i32(Mo), i32(No), i32(T), f32(1.0), i32(-160), vp(0), vp(st))
+            assert rc == 0, rc
+        res = {k: [] for k in libs}
+        for k, lib in libs.items():
+            for _ in range(3):
+                call_tn(lib)
+        torch.cuda.synchronize()
+        for rnd in range(7):
+            for k, lib in libs.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    call_tn(lib)
+                e1.record()
+                torch.cuda.synchronize()
+                res[k].append(e0.elapsed_time(e1) / 10 * 1e3)
+        print(f"{sname} {Mo}x{No} T{T} @160: " + "  ".join(f"{k} {statistics.median(v):.1f}" for k, v in res.items()), flush=True)
 
 
 if __name__ == "__main__":

@@ -204,7 +204,7 @@ def plan_buckets(segment_ends: List[int], bucket_elems: int, tail_elems: int = 0
     buckets, lo = [], 0
     total = segment_ends[-1] if segment_ends else 0
     for end in segment_ends:
-        want = tail_bucket_elems if (tail_bucket_elems and total - end < tail_elems) else bucket_elems
+        want = min(tail_bucket_elems, bucket_elems) if (tail_bucket_elems and total - end < tail_elems) else bucket_elems
         if end - lo >= want:
             buckets.append((lo, end))
             lo = end

@@ -214,6 +214,11 @@ def test_two_ranks_on_one_gpu_with_a_sharded_optimizer(hip):
 def test_two_ranks_over_rccl(hip):
     r = _ranks(2, "tools/dp_check.py")
     assert r.returncode == 0 and "DP2 OK (nccl)" in r.stdout[0], r.tail()
+    # the sharded optimizer's REAL multi-rank path - in-place reduce_scatter_tensor into a slice of its own input, in-place
+    # all_gather_into_tensor, ownership of piece r of every bucket for r > 0 - has run over gloo and in one-rank groups only:
+    # the first box with two GPUs exercises it here
+    r = _ranks(2, "tools/dp_check.py", env={"STONK_DP_SHARD": "1"})
+    assert r.returncode == 0 and "DP2 OK (nccl, sharded optimizer)" in r.stdout[0], r.tail()
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")

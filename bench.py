@@ -25,10 +25,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM-side bytes per launch of the dominant kernel, from separate rocprofv3 --pmc passes over this command:
-# gemm_tn_a4_kernel (12L/768, average of its 46 launches per step on the unpadded rows): FETCH_SIZE doubled (the gfx950
-# correction of MI355X_MICROARCH.md) + WRITE_SIZE (float atomics), profiles/r04_pmc_traffic.csv; algorithmic: 193.5 MB.
+# gemm_tn_a4_kernel (12L/768, average of its 46 launches per step on the unpadded rows): 250.0 MB fetched (FETCH_SIZE
+# doubled, the gfx950 correction of MI355X_MICROARCH.md) + 60.0 MB of float atomics written (WRITE_SIZE),
+# profiles/r04_pmc_traffic.csv; algorithmic: 193.5 MB.
 # (round 3, gemm_tn_w4_kernel: 242.7 + 58.6 = 301.3 MB)
-TRAFFIC_BYTES = {("150k", "tn_a4"): None}
+TRAFFIC_BYTES = {("150k", "tn_a4"): 310.0e6}
 KERNEL_NOTES = {
     "tn_a4": "gemm_tn_a4_kernel (weight + bias gradients: bf16 MFMA 16x16x32, 256x256 tiles over 64-token steps, four waves, "
              "LDS-DMA operands, transposed LDS reads, a written-out K loop, split-K fp32 buffer atomics)",

@@ -1,7 +1,9 @@
 // bf16 MFMA GEMM, 256 x (256 | 192) x 64 tiles, FOUR waves per workgroup (one per SIMD, 128 x 128 | 96 wave tiles),
 // v_mfma_f32_16x16x32_bf16, operands by LDS-DMA (buffer_load ... lds), and a K loop whose instruction stream is
 // WRITTEN OUT: tools/gen_gemm_a4.py generates gemm_a4_loop.inc, one inline-assembly block per output tile.
-// Same contract as gemm_bf16.hip (C = epilogue(A[M,K] . B[N,K]^T)), bf16 output, alpha = 1, no K split.
+// Same contract as gemm_bf16.hip (C = epilogue(A[M,K] . B[N,K]^T)): bf16 output with the fused epilogues (alpha = 1, no K
+// split), and the two forms the label-sparse decoders launch - fp16 output of the plain product (the logits) and
+// C (fp32) += alpha * product over a SPLIT contraction through float atomics (d hidden = d logits . W, K = the vocabulary).
 //
 // Why a fourth NT kernel: gemm_w4.hip has this geometry in compiled C++ and keeps the matrix pipe
 // 54-64 % busy - with one wave per SIMD every instruction that is not in an MFMA's shadow delays the next MFMA, and the
@@ -36,6 +38,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct Work {
   int m0, n0;
+  int k0, nk;   // the item's K tiles: [k0, k0 + nk), nk even
 };
 
 // Exact (erf) GELU and its derivative on PAIRS of values: gelu(x) = x Phi(x), gelu'(x) = Phi(x) + x phi(x), with
@@ -78,6 +81,19 @@ __device__ __forceinline__ void gelu8(float (&v)[8], float (&u)[8]) {
 #undef STONK_A4_STAGE
 }
 
+// eight fp32 -> eight IEEE fp16, saturated at +-65504 as to_f16_sat (common.h) does
+__device__ __forceinline__ u32x4 pack8h(const float* e) {
+  typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+  union {
+    u32x4 v;
+    f16x2_ h[4];
+  } u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    u.h[j] = __builtin_convertvector((f32x2_){fminf(fmaxf(e[2 * j], -65504.f), 65504.f), fminf(fmaxf(e[2 * j + 1], -65504.f), 65504.f)}, f16x2_);
+  return u.v;
+}
+
 // eight fp32 -> eight bf16 by four v_cvt_pk_bf16_f32 (element-wise casts into a vector cost a conversion AND a v_perm each)
 __device__ __forceinline__ bf16x8 pack8(const float* e) {
   typedef bf16 bf16x2_ __attribute__((ext_vector_type(2)));
@@ -111,8 +127,20 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
   }
   const int N = p.N;
   const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
-  const int nk = p.K / BK;            // even, >= 2 (launcher)
-  const int total = ntm * ntn;
+  // K tiles per work item: all of them, or (split_k > 1: the atomic output) an even share - the last item of a tile takes
+  // what is left (even as well: K / 64 is)
+  // split_k is an upper bound: with a device-side row count the number of tiles is known here only, and more items than
+  // workgroups would run as a second, mostly empty round (20 tiles x 13 shares on 256 CUs: 12 shares fill one round)
+  const int nk_all = p.K / BK;        // even, >= 2 (launcher)
+  const int tiles_mn = ntm * ntn;
+  int sk = p.split_k;
+  if (sk > 1 && tiles_mn > 0) {
+    const int fit = gridDim.x / tiles_mn;
+    sk = sk < fit ? sk : (fit > 1 ? fit : 1);
+  }
+  const int per = sk > 1 ? ((nk_all + 2 * sk - 1) / (2 * sk)) * 2 : nk_all;
+  const int nsp = (nk_all + per - 1) / per;
+  const int total = tiles_mn * nsp;   // (the tiles of one K share are neighbours: they share operand panels in an XCD's L2)
   const int G = gridDim.x;
 
   // work item -> tile; the items of one round that the workgroups of one XCD take are neighbours (as gemm_w4.hip)
@@ -126,6 +154,10 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
       if (s >= q + (x < rem ? 1 : 0)) return false;
       idx = r * G + x * q + (x < rem ? x : rem) + s;
     }
+    const int sp = nsp > 1 ? idx / tiles_mn : 0;
+    idx -= sp * tiles_mn;
+    o.k0 = sp * per;
+    o.nk = nk_all - o.k0 < per ? nk_all - o.k0 : per;
     int rt, ct;
     if (ntm >= ntn) {
       rt = idx / ntn;
@@ -171,11 +203,13 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
     raB[h] = (int)lds0 + 2 * IMG_BYTES + wc * (BN_ / 2) * 128 + o;
   }
 
+  // (extents: the tile's own rows only - 256 x ld bytes always fits 32 bits, M x ld need not)
   auto cursor_of = [&](const Work& w, i32x4& a, i32x4& b) {
-    const unsigned long pa = (unsigned long)p.A + (unsigned long)((long)w.m0 * lda2);
-    const unsigned long pb = (unsigned long)p.B + (unsigned long)((long)w.n0 * ldb2);
-    a = (i32x4){(int)(unsigned)pa, (int)((pa >> 32) & 0xffff), (M - w.m0) * lda2, 0x00020000};
-    b = (i32x4){(int)(unsigned)pb, (int)((pb >> 32) & 0xffff), (N - w.n0) * ldb2, 0x00020000};
+    const unsigned long pa = (unsigned long)p.A + (unsigned long)((long)w.m0 * lda2) + (unsigned long)(w.k0 * (BK * 2));
+    const unsigned long pb = (unsigned long)p.B + (unsigned long)((long)w.n0 * ldb2) + (unsigned long)(w.k0 * (BK * 2));
+    const int ra = M - w.m0 < BM ? M - w.m0 : BM, rb = N - w.n0 < BN ? N - w.n0 : BN;
+    a = (i32x4){(int)(unsigned)pa, (int)((pa >> 32) & 0xffff), ra * lda2 - w.k0 * (BK * 2), 0x00020000};
+    b = (i32x4){(int)(unsigned)pb, (int)((pb >> 32) & 0xffff), rb * ldb2 - w.k0 * (BK * 2), 0x00020000};
   };
 
   Work cw, nw;
@@ -196,9 +230,12 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
   else
     asm volatile(STONK_A4_PROLOGUE_192 : "+{s[36:39]}"(curA), "+{s[40:43]}"(curB) : STONK_A4_VOFF_OPERANDS : "m0", "scc", "memory");
 
-  const int flags = EPI;
-  const int ldc_b = (int)p.ldc * 2, ldr_b = (int)p.ldr * 2, ldx_b = (int)p.ldaux * 2;
-  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, M * ldc_b, 0x00020000);
+  constexpr int OUT = EPI & STONK_EPI_OUT_MASK;
+  static_assert(OUT == STONK_EPI_OUT_BF16 || ((OUT == STONK_EPI_OUT_F16 || OUT == STONK_EPI_OUT_F32_ATOMIC) && (EPI & ~STONK_EPI_OUT_MASK) == 0),
+                "fp16 / atomic fp32 output: the plain product");
+  constexpr int CB = OUT == STONK_EPI_OUT_F32_ATOMIC ? 4 : 2;   // bytes per output element
+  const int flags = EPI & ~STONK_EPI_OUT_MASK;
+  const int ldc_b = (int)p.ldc * CB, ldr_b = (int)p.ldr * 2, ldx_b = (int)p.ldaux * 2;
   const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, M * ldr_b, 0x00020000);
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.aux, 0, M * ldx_b, 0x00020000);
   const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, N * 4, 0x00020000);
@@ -215,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
     i32x4 nxA, nxB;
     cursor_of(more ? nw : cw, nxA, nxB);   // (no next tile: the cursor re-reads this tile's first K tiles, never consumed)
     f32x16 acc[16];
-    int rem = nk >> 1;
+    int rem = cw.nk >> 1;
     // the bias of this lane's columns: requested before the K loop, used after it
     f32x4 bq[NJP][2];
     if (flags & STONK_EPI_BIAS) {
@@ -264,6 +301,10 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
     for (int g = 0; g < NACC; ++g) asm volatile("" : "+a"(acc[g]));
     // ---- epilogue: row block i (16 rows: a lane's row is r16), column-block pair jp -> 8 consecutive columns per lane
     const int wm0 = cw.m0 + wr * 128, wn0 = cw.n0 + ncol;
+    // the output through a buffer that starts at the tile's first row and ends with its last one (M x ldc bytes need not
+    // fit 32 bits: 16 384 rows of 175 104 logits)
+    const int crows = M - cw.m0 < BM ? M - cw.m0 : BM;
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((char*)p.C + (long)cw.m0 * ldc_b, 0, crows * ldc_b, 0x00020000);
     bf16x8 sd[NJP];
     auto side_request = [&](const int i) {
       if (!SIDE) return;
@@ -350,7 +391,15 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
         so.aux = so.res = cur[jp];
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         epilogue8_pre(v, p, rest & ~STONK_EPI_SAVE_PREACT, m, n, z4, z4, so);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pack8(v)), rC, m * ldc_b + n * 2 + oob, 0, 0);
+        const int co = (m - cw.m0) * ldc_b + n * CB + oob;
+        if (OUT == STONK_EPI_OUT_F32_ATOMIC) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v[e] * p.alpha, rC, co + 4 * e, 0, 0);
+        } else if (OUT == STONK_EPI_OUT_F16) {
+          __builtin_amdgcn_raw_buffer_store_b128(pack8h(v), rC, co, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pack8(v)), rC, co, 0, 0);
+        }
       }
     }
     if (!more) break;
@@ -376,8 +425,11 @@ int launch_a4(const GemmArgs& a, int grid, hipStream_t st) {
 
 }  // namespace
 
-// Launcher used by stonk_gemm_nt_bf16 (gemm_bf16.hip). Requires bf16 output, alpha == 1, split_k == 1, K % 128 == 0, ld % 64 == 0,
-// 32-bit operand extents, 16-byte aligned side operands. tile_n: 0 = choose, 256, 192. items_per_wg as gemm_w4.hip.
+// Launcher used by stonk_gemm_nt_bf16 (gemm_bf16.hip). Requires K % 128 == 0, ld % 64 == 0, 256 rows of every operand within
+// 2^30 bytes, 16-byte aligned side operands; bf16 output: alpha == 1 and split_k == 1; fp16 output: the same, no epilogue;
+// atomic fp32 output: no epilogue, alpha as given, split_k an upper bound (the kernel takes as many shares as fill the grid
+// once; a share is rounded up to an even number of K tiles).
+// tile_n: 0 = choose, 256, 192. items_per_wg as gemm_w4.hip.
 // Returns STONK_ESHAPE for an epilogue this kernel has no instance of (the caller then takes another kernel).
 int stonk_gemm_a4_launch(const GemmArgs& a, int tile_n, int items_per_wg, hipStream_t st) {
   static int n_cu = 0;
@@ -390,16 +442,25 @@ int stonk_gemm_a4_launch(const GemmArgs& a, int tile_n, int items_per_wg, hipStr
   constexpr int B = STONK_EPI_BIAS, G = STONK_EPI_GELU, SV = STONK_EPI_SAVE_PREACT, GB = STONK_EPI_GELU_BWD,
                 R = STONK_EPI_RESID, D = STONK_EPI_DROPOUT, AG = STONK_EPI_AUX_GRAD;
   const int epi = a.flags & (B | G | SV | GB | R | D | AG);
+  const int out = a.flags & STONK_EPI_OUT_MASK;
+  if (out != STONK_EPI_OUT_BF16 && (epi != 0 || out == STONK_EPI_OUT_F32)) return STONK_ESHAPE;
   const long ntm = (a.M + BM - 1) / BM;
-  const bool has192 = a.N % 192 == 0 && (epi == 0 || epi == B || epi == R || epi == (B | R) || epi == (B | R | D));
+  const bool has192 = a.N % 192 == 0 && out != STONK_EPI_OUT_F16 &&
+                      (epi == 0 || epi == B || epi == R || epi == (B | R) || epi == (B | R | D));
   if (tile_n == 192 && !has192) return STONK_ESHAPE;
+  const int nk_all = a.K / BK;
+  const int per = a.split_k > 1 ? ((nk_all + 2 * a.split_k - 1) / (2 * a.split_k)) * 2 : nk_all;
+  const long nsp = (nk_all + per - 1) / per;   // (as the kernel counts them)
   if (tile_n == 0) {
-    const long t256 = ntm * ((a.N + 255) / 256), t192 = ntm * (a.N / 192);
+    const long t256 = ntm * ((a.N + 255) / 256) * nsp, t192 = ntm * (a.N / 192) * nsp;
     const long c256 = ((t256 + n_cu - 1) / n_cu) * 256, c192 = ((t192 + n_cu - 1) / n_cu) * 192;
     tile_n = (has192 && c192 < c256) ? 192 : 256;
   }
-  const long tiles = tile_n == 192 ? ntm * (a.N / 192) : ntm * ((a.N + 255) / 256);
+  const long tiles = (tile_n == 192 ? ntm * (a.N / 192) : ntm * ((a.N + 255) / 256)) * nsp;
   const int grid = (int)(items_per_wg > 0 ? (tiles + items_per_wg - 1) / items_per_wg : (tiles < n_cu ? tiles : n_cu));
+  if (out == STONK_EPI_OUT_F16) return launch_a4<STONK_EPI_OUT_F16, 256>(a, grid, st);
+  if (out == STONK_EPI_OUT_F32_ATOMIC)
+    return tile_n == 192 ? launch_a4<STONK_EPI_OUT_F32_ATOMIC, 192>(a, grid, st) : launch_a4<STONK_EPI_OUT_F32_ATOMIC, 256>(a, grid, st);
   if (tile_n == 192) {
     switch (epi) {
       case 0: return launch_a4<0, 192>(a, grid, st);

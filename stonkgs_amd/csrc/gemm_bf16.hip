@@ -377,8 +377,16 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
         // has 256x192 tiles: 42.6 against 52.3 us (tools/bench_w4_tiles.py)
         : (w4_ok && M >= 1024 && N % 192 == 0 && out_mode == STONK_EPI_OUT_BF16 && (flags & 0x1FC) == 0) ? STONK_GEMM_WAVE4
                                                                              : STONK_GEMM_TILE128;
-  // the written-out four-wave kernel (gemm_a4.hip): bf16 output, no K split, no device-side K, one side operand at most
-  const bool a4_ok = w4_ok && out_mode == STONK_EPI_OUT_BF16 && split_k == 1 && (K / BK) >= 2 && alpha == 1.0f;
+  // the written-out four-wave kernel (gemm_a4.hip): no device-side K, one side operand at most; bf16 output with the fused
+  // epilogues (no K split, alpha = 1), or the plain product as fp16, or as fp32 added atomically over a K split. Its
+  // buffers start at a tile's first row: 256 rows of an operand must fit 2^30 bytes, the whole operand need not (16 384
+  // x 175 104 logits)
+  const bool a4_plain = (flags & 0x1FC) == 0;
+  const bool a4_ok = ldc % 8 == 0 && !both_sides && !k_dev && (K / BK) % 2 == 0 && lda % 64 == 0 && ldb % 64 == 0 &&
+                     lda < (1L << 20) && ldb < (1L << 20) && ldc < (1L << 20) &&
+                     (out_mode == STONK_EPI_OUT_BF16 ? (w4_ok && split_k == 1 && alpha == 1.0f)
+                      : out_mode == STONK_EPI_OUT_F16 ? (a4_plain && alpha == 1.0f)
+                      : out_mode == STONK_EPI_OUT_F32_ATOMIC ? a4_plain : false);
   if (k == STONK_GEMM_ASM4 || k == STONK_GEMM_ASM4_192) {
     STONK_CHECK_ARG(a4_ok, STONK_ESHAPE);
     return stonk_gemm_a4_launch(a, k == STONK_GEMM_ASM4 ? 256 : 192, 0, st);
@@ -387,7 +395,8 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   // instance of goes there (round 4, tools/a4_probe.py at 26 432 rows, alone, us: QKV 89 against 106 on the compiled
   // four-wave kernel, attention-output 41 / 49, FFN-up 166 -> see profiles/ / 186, FFN-down 107 / 124, dgrad through GELU'
   // 152 / 157, dgrad + residual 105 / 119 and 82 / 92, plain 768 x 768 36 / 39); it picks its tile width itself
-  if ((kernel == STONK_GEMM_AUTO || dispatched) && a4_ok && M >= 1024) {
+  // (fp16 logits too: round 4, the entity decoder 830 -> see profiles/ us; the atomic form only where the caller names it)
+  if ((kernel == STONK_GEMM_AUTO || dispatched) && a4_ok && M >= 1024 && out_mode != STONK_EPI_OUT_F32_ATOMIC) {
     const int rc = stonk_gemm_a4_launch(a, 0, !dispatched ? 0 : (kernel == STONK_GEMM_DISPATCHED2 ? 2 : 1), st);
     if (rc != STONK_ESHAPE) return rc;   // (an epilogue it has no instance of: the older kernels below)
   }

@@ -136,16 +136,34 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const LT* __restrict_
     const LT* x = logits + (long)row * ld;
     float m = -3.0e38f, s = 0.f;
     const int n8 = ncols >> 3;
-    for (int i = t; i < n8; i += 256) {
-      float v[8];
-      LogitVec<LT>::load8(x + 8 * i, v);
-      const float vm = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+    // four 16-byte (fp32: 32-byte) pieces per thread and iteration, all requested before the first is used: with one
+    // load in flight per thread the sweep ran at the memory LATENCY (5 rows per CU x 4 KB: 2.5 TB/s on the entity
+    // decoder's 350-KB rows); a piece past the row's end counts as -inf (exp = 0)
+    for (int i0 = 0; i0 < n8; i0 += 1024) {
+      float v[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 256 * u + t;
+        if (i < n8) {
+          LogitVec<LT>::load8(x + 8 * i, v[u]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[u][j] = -__builtin_inff();
+        }
+      }
+      float vm = v[0][0];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vm = fmaxf(vm, v[u][j]);
       if (vm > m) {
         s *= __expf(m - vm);
         m = vm;
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += __expf(v[j] - m);
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += __expf(v[u][j] - m);
     }
     for (int i = (n8 << 3) + t; i < ncols; i += 256) {
       const float v = (float)x[i];
@@ -181,29 +199,45 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const LT* __restrict_
     if (t == 0) atomicAdd(loss_sum, lse - (float)x[tgt]);
     if (dlogits) {
       bf16* d = dlogits + (long)row * ld_d;
-      const int p8 = npad >> 3;
-      for (int i = t; i < p8; i += 256) {
+      const int p8 = npad >> 3, f8 = ncols >> 3;   // whole pieces of the row: [0, f8); [f8, p8) holds the row's end and the padding
+      const float nlse = -lse;
+      for (int i0 = 0; i0 < f8; i0 += 1024) {   // (four pieces in flight per thread, as above)
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + 256 * u + t;
+          if (i < f8) LogitVec<LT>::load8(x + 8 * i, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + 256 * u + t;
+          if (i >= f8) continue;
+          const int c0 = i * 8;
+          float pr[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pr[j] = __expf(v[u][j] + nlse);
+          if (tgt >= c0 && tgt < c0 + 8) {   // (one piece of the row)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (c0 + j == tgt) pr[j] -= 1.f;
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (bf16)(pr[j] * g);
+          *(bf16x8*)(d + c0) = o;
+        }
+      }
+      for (int i = f8 + t; i < p8; i += 256) {
         const int c0 = i * 8;
         bf16x8 o;
-        if (c0 + 8 <= ncols) {
-          float v[8];
-          LogitVec<LT>::load8(x + c0, v);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float pr = __expf(v[j] - lse);
+        for (int j = 0; j < 8; ++j) {
+          float pr = 0.f;
+          if (c0 + j < ncols) {
+            pr = __expf((float)x[c0 + j] - lse);
             if (c0 + j == tgt) pr -= 1.f;
-            o[j] = (bf16)(pr * g);
           }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float pr = 0.f;
-            if (c0 + j < ncols) {
-              pr = __expf((float)x[c0 + j] - lse);
-              if (c0 + j == tgt) pr -= 1.f;
-            }
-            o[j] = (bf16)(pr * g);
-          }
+          o[j] = (bf16)(pr * g);
         }
         *(bf16x8*)(d + c0) = o;
       }

@@ -93,6 +93,11 @@ class Engine:
         # prefetch; measured on one GPU with nothing beside it (tools/ab_step.py dispatched_pairs engine.comm_overlap=1)
         self.dispatched_pairs = True
         self.decoder_dgrad_256 = True
+        # the label-sparse decoders' dgrad on gemm_a4.hip (fp32 atomics over a K split): measured SLOWER than the eight-wave
+        # kernel at these shapes - rows 58 / 350 KB apart, 737 against 612 us (entity) and 349 against 148 (text),
+        # tools/decoder_probe.py - so off; the decoders' FORWARD (fp16 logits) does run there: 687 against 888, 128 / 168
+        self.decoder_dgrad_a4 = False
+        self.decoder_fwd_a4 = True     # (False: the eight-wave kernel, as before round 4)
         # Which of the library's three NT kernels runs a launch is the LIBRARY's choice (STONK_GEMM_AUTO: from shape and
         # epilogue, stonk_gemm_nt_bf16) - except where the engine knows what the library cannot: that an all-reduce is
         # running beside backward (comm_overlap -> the dynamically scheduled 128x128 kernel for the persistent launches).
@@ -823,7 +828,8 @@ class Engine:
                 # decoder GEMM writes and the cross-entropy reads 2 bytes per logit instead of 4 - both are HBM-bound on them
                 f16 = self.f16_logits
                 logits = self.buf(f"l.{nm}.logits", (cap, npad), torch.float16 if f16 else F32)
-                self.gemm(hs, w(wname), logits, cap, npad, H, flags=hip.EPI_OUT_F16 if f16 else hip.EPI_OUT_F32, m_dev=cnt)
+                self.gemm(hs, w(wname), logits, cap, npad, H, flags=hip.EPI_OUT_F16 if f16 else hip.EPI_OUT_F32, m_dev=cnt,
+                          kernel=hip.GEMM_AUTO if self.decoder_fwd_a4 else hip.GEMM_WAVE8)
                 dl = self.buf(f"l.{nm}.dl", (cap, npad)) if need_backward else None
                 hip.call("stonk_softmax_xent_f16_fwd_bwd" if f16 else "stonk_softmax_xent_fwd_bwd", logits.data_ptr(), npad,
                          N, npad, tg.data_ptr(), cnt.data_ptr(), acc[hi:hi + 1].data_ptr(), hip.ptr(dl), npad, 1.0, cap,
@@ -893,7 +899,12 @@ class Engine:
             # tiles with 16: 734 us against 951 for the entity decoder (tools/bench_decoder_dgrad.py)
             # (not beside a running all-reduce - the entity decoder's bucket is in flight when the text decoder's dgrad is
             # launched: a persistent launch would wait for the CUs RCCL holds, tools/hog_test.py)
-            if (self.decoder_dgrad_256 and npad >= 16384 and cap >= 1024 and H % 256 == 0
+            # (the written-out four-wave kernel on 256x192 tiles with as many K shares as fill the CUs once - it counts the
+            # live tiles itself, split_k is an upper bound - is the slower one here: see __init__)
+            if self.decoder_dgrad_a4 and cap >= 1024 and H % 192 == 0 and (npad // 64) % 2 == 0 and not (self.comm_overlap and nm != "ent"):
+                self.gemm(h["dl"], wt[wname], dhs, cap, H, npad, flags=hip.EPI_OUT_F32_ATOMIC, split_k=64, m_dev=h["cnt"],
+                          alpha=gscale, kernel=hip.GEMM_ASM4_192)
+            elif (self.decoder_dgrad_256 and npad >= 16384 and cap >= 1024 and H % 256 == 0
                     and not (self.comm_overlap and nm != "ent")):
                 self.gemm(h["dl"], wt[wname], dhs, cap, H, npad, flags=hip.EPI_OUT_F32_ATOMIC, split_k=8, m_dev=h["cnt"],
                           alpha=gscale, kernel=hip.GEMM_WAVE8)

@@ -465,3 +465,47 @@ def test_written_out_four_wave_kernel(hip, kernel, M, N, K):
     if K >= 192:
         with pytest.raises(hip.StonkHipError, match="-2"):
             _gemm(hip, A[:, :K - 64], B[:, :K - 64], kernel=kernel)
+
+
+@pytest.mark.parametrize("M,N,K,cut", [(1000, 768, 128, None), (4096, 29056, 768, 2427), (16384, 70016, 128, None)])
+def test_written_out_kernel_fp16_logits(hip, M, N, K, cut):
+    """The label-sparse decoders' forward on the written-out kernel (explicitly, and as AUTO takes it): the fp32 product
+    rounded once to fp16, saturated; a device-side row count leaves the rows past it alone; an output of more than 2^31
+    bytes (the entity decoder's 16 384 x 175 104 capacity) is addressed from each tile's first row."""
+    A, B = _rand((M, K), 0.5, 81), _rand((N, K), 0.5, 82)
+    m_dev = None if cut is None else torch.tensor([cut], device="cuda", dtype=torch.int32)
+    rows = M if cut is None else cut
+    for kernel in (ASM4, 0):
+        C = torch.full((M, N), -7.0, device="cuda", dtype=torch.float16)
+        _gemm(hip, A, B, flags=hip.EPI_OUT_F16, C=C, m_dev=m_dev, kernel=kernel)
+        for r0 in range(0, rows, 4096):   # (in slabs: the fp32 reference of the largest case is 4.6 GB)
+            r1 = min(rows, r0 + 4096)
+            ref = (A[r0:r1].float() @ B.float().t()).half()
+            torch.testing.assert_close(C[r0:r1].float(), ref.float(), rtol=1e-3, atol=1e-3)
+        assert (C[rows:] == -7.0).all()
+    big = torch.full((256, 128), 200.0, device="cuda", dtype=torch.bfloat16)
+    Bb = big[:128].clone()
+    Bb[1] = -200.0
+    out = _gemm(hip, big, Bb, torch.float16, flags=hip.EPI_OUT_F16, kernel=ASM4)   # 128 * 200 * 200 > 65504
+    assert torch.isfinite(out).all() and float(out[0, 0]) == 65504.0 and float(out[0, 1]) == -65504.0
+    with pytest.raises(hip.StonkHipError, match="-2"):
+        _gemm(hip, A, B, torch.float16, flags=hip.EPI_OUT_F16, kernel=ASM4_192)
+
+
+@pytest.mark.parametrize("kernel", [ASM4, ASM4_192])
+@pytest.mark.parametrize("M,N,K,sk,cut", [(768, 768, 8192, 8, None), (304, 1536, 4096, 16, None), (300, 768, 4224, 5, None),
+                                          (2048, 768, 175104, 13, 1229), (2048, 768, 29056, 8, 2040)])
+def test_written_out_kernel_split_k_atomic(hip, kernel, M, N, K, sk, cut):
+    """The decoders' dgrad form: C (fp32) += alpha * A . B^T over a split contraction (a split's share is rounded up to an even
+    number of K tiles: 66 K tiles in 5 splits = 14 + 14 + 14 + 14 + 10), device-side row count, 175 104-long contraction."""
+    A, B = _rand((M, K), 0.3, 83), _rand((N, K), 0.3, 84)
+    m_dev = None if cut is None else torch.tensor([cut], device="cuda", dtype=torch.int32)
+    rows = M if cut is None else cut
+    C = torch.ones(M, N, device="cuda")
+    _gemm(hip, A, B, flags=hip.EPI_OUT_F32_ATOMIC, kernel=kernel, split_k=sk, C=C, m_dev=m_dev, alpha=0.5)
+    ref = 1.0 + 0.5 * (A[:rows].float() @ B.float().t())
+    torch.testing.assert_close(C[:rows], ref, rtol=1e-4, atol=2e-3 * (K / 2048) ** 0.5)
+    assert (C[rows:] == 1.0).all()
+    C1 = torch.zeros(M, N, device="cuda")
+    _gemm(hip, A, B, flags=hip.EPI_OUT_F32_ATOMIC, kernel=kernel, split_k=1, C=C1, m_dev=m_dev)
+    torch.testing.assert_close(C1[:rows], A[:rows].float() @ B.float().t(), rtol=1e-4, atol=2e-3 * (K / 2048) ** 0.5)

@@ -169,28 +169,32 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int c0, in
 struct Stage2 {
   bf16x8 c[2];
 };
-// rows row0 .. row0+63 of the sequence that starts at `base`; rows past the sequence's last one (n - 1) re-read that one:
-// finite values the callers mask out (a packed sequence's length need not be a multiple of the tile). The tile origin is a
-// scalar product and the per-thread row offsets are loop invariants; only a sequence's ragged LAST tile pays for clamping
-// (a per-load 64-bit multiply here cost the forward kernel 15-20 %).
-__device__ __forceinline__ void stage_load(Stage2& s, const bf16* base, long ld, int row0, int n, int tid) {
-  const bf16* origin = base + (long)__builtin_amdgcn_readfirstlane(row0) * ld;
-  if (row0 + TK <= n) {
+// rows row0 .. row0+63 of the sequence that starts at `base`, through a buffer that begins at the tile's first row and
+// ends with the sequence's last one: rows past it arrive as ZEROS - finite values the callers mask out (a packed
+// sequence's length need not be a multiple of the tile). The descriptor is scalar arithmetic per tile and the per-thread
+// offsets (TileOff) are two loop-invariant registers per row stride: with per-thread 64-bit addresses the compiler
+// rebuilt row * ld for every load of every tile - 13 v_lshl_add_u64, 8 v_mul_lo_u32 and 4 v_mad_u64_u32 per tile, a fifth
+// of the forward kernel's vector instructions (tools/isa_mix.py).
+struct TileOff {
+  int o[2];
+};
+__device__ __forceinline__ TileOff tile_voff(long ld, int tid) {
+  TileOff t;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int id = tid + 256 * i;
-      s.c[i] = *(const bf16x8*)(origin + (long)(id >> 3) * ld + (id & 7) * 8);
-    }
-  } else {
-    const int last = n - 1 - row0;   // >= 0: the caller only asks for tiles that start inside the sequence
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int id = tid + 256 * i;
-      int r = id >> 3;
-      r = r < last ? r : last;
-      s.c[i] = *(const bf16x8*)(origin + (long)r * ld + (id & 7) * 8);
-    }
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 256 * i;
+    t.o[i] = (id >> 3) * (int)(ld * 2) + (id & 7) * 16;
   }
+  return t;
+}
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+__device__ __forceinline__ void stage_load(Stage2& s, const bf16* base, long ld, int row0, int n, const TileOff& vo) {
+  row0 = __builtin_amdgcn_readfirstlane(row0);
+  const int rows = n - row0 < TK ? n - row0 : TK;   // >= 1: the caller only asks for tiles that start inside the sequence
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)row0 * ld), 0, (rows - 1) * (int)(ld * 2) + ROWB, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) s.c[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, vo.o[i], 0, 0));
 }
 __device__ __forceinline__ void stage_store(const Stage2& s, char* tile, int tid) {
 #pragma unroll
@@ -279,17 +283,30 @@ __device__ __forceinline__ void live_issue(LiveTiles& t, const long* mask, long 
     t.mv[c] = key < S ? mask[tok0 + key] : 0;   // (S: the rows of THIS sequence)
   }
 }
+// With `kbias` (forward, dQ): the additive bias of EVERY key of the sequence (0, or NEG_MASK for a masked key and for the
+// keys past the sequence's end) goes to LDS here, once - the tile loop reads it from there instead of loading and
+// converting a tile's 64 mask words with every tile (a load per tile whose 64-bit word also cost the forward kernel
+// the two registers that pushed it into scratch).
 template <bool HAS_MASK>
-__device__ __forceinline__ uint64_t live_finish(const LiveTiles& t, int S, int tid) {
-  const int nt = (S + TK - 1) / TK;
+__device__ __forceinline__ uint64_t live_finish(const LiveTiles& t, const long* mask, long tok0, int n, int S, int tid,
+                                                float* kbias) {
+  const int nt = (n + TK - 1) / TK;
   const uint64_t all = nt >= 64 ? ~0ull : ((1ull << nt) - 1);
-  if (!HAS_MASK || S > 1024) return all;
+  if (!HAS_MASK) return all;
+  if (S > 1024) {   // (no tile skipping beyond 1024 keys: the words are only turned into the bias)
+    if (kbias) {
+      for (int key = tid; key < S; key += 256) kbias[key] = (key < n && mask[tok0 + key] != 0) ? 0.f : NEG_MASK;
+      __syncthreads();
+    }
+    return all;
+  }
   __shared__ int tile_live[16];
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const uint64_t b = __ballot(t.mv[c] != 0);
     if (lane == 0) tile_live[c * 4 + wave] = b != 0;
+    if (kbias && c * 256 + tid < S) kbias[c * 256 + tid] = t.mv[c] != 0 ? 0.f : NEG_MASK;
   }
   __syncthreads();
   const uint64_t m = __ballot(lane < nt && tile_live[lane & 15] != 0);
@@ -301,6 +318,7 @@ __device__ __forceinline__ uint64_t live_finish(const LiveTiles& t, int S, int t
 template <bool HAS_MASK, bool DROPOUT>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGEB];
+  extern __shared__ __attribute__((aligned(16))) float kbias[];   // [S] with a mask (dynamic: the launcher sizes it)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const AttnBlock blk = attn_block();
@@ -314,7 +332,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
   LiveTiles lt;
   live_issue<HAS_MASK>(lt, p.mask, tok0, n, tid);
 
-  const int qr = q0 + r < n ? q0 + r : n - 1;   // rows past the sequence re-read its last row; nothing is stored for them
+  const int qr = q0 + r < n ? q0 + r : n - 1;   // query rows past the sequence re-read its last row; nothing is stored for them
   bf16x8 qf[4];
   {
     const bf16* qrow = p.q + (tok0 + qr) * p.ld + h * HD;
@@ -335,20 +353,18 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
   if (DROPOUT) c2u = c2_of_row(r);
 
   Stage2 sk, sv;
-  long mreg = 1;
+  const TileOff vo = tile_voff(p.ld, tid);
   auto load_tile = [&](int kt) {
-    stage_load(sk, kbase, p.ld, kt * TK, n, tid);
-    stage_load(sv, vbase, p.ld, kt * TK, n, tid);
-    if (HAS_MASK && tid < TK) mreg = kt * TK + tid < n ? p.mask[tok0 + kt * TK + tid] : 0;   // keys past the end: masked
+    stage_load(sk, kbase, p.ld, kt * TK, n, vo);
+    stage_load(sv, vbase, p.ld, kt * TK, n, vo);
   };
   auto store_tile = [&](int buf) {
     char* base = lds + buf * STAGEB;
     stage_store(sk, base, tid);
     stage_store(sv, base + TILEB, tid);
-    if (HAS_MASK && tid < TK) ((float*)(base + 2 * TILEB))[tid] = mreg != 0 ? 0.f : NEG_MASK;
   };
   load_tile(0);   // (before the live bits are known: tile 0 almost always is - [CLS])
-  uint64_t rem = live_finish<HAS_MASK>(lt, n, tid);
+  uint64_t rem = live_finish<HAS_MASK>(lt, p.mask, tok0, n, S, tid, kbias);
   if (rem == 0) rem = ntiles >= 64 ? ~0ull : ((1ull << ntiles) - 1);
   int kt = __builtin_ctzll(rem);
   rem &= rem - 1;
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
   for (int it = 0;; ++it) {   // the live key tiles, in order
     const char* Ks = lds + (it & 1) * STAGEB;
     const char* Vs = Ks + TILEB;
-    const float* Mb = (const float*)(Ks + 2 * TILEB);
+    const float* Mb = kbias + kt * TK;   // (the sequence's key bias, written once by live_finish)
     const int nx = rem ? __builtin_ctzll(rem) : -1;
     rem &= rem - 1;
     if (nx >= 0) load_tile(nx);
@@ -474,6 +490,7 @@ __global__ __launch_bounds__(128) void attn_delta_kernel(const AttnArgs p) {
 template <bool HAS_MASK, bool DROPOUT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGEB];
+  extern __shared__ __attribute__((aligned(16))) float kbias[];   // [S] with a mask
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const AttnBlock blk = attn_block();
@@ -522,20 +539,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   if (DROPOUT) c2u = c2_of_row(r);
 
   Stage2 sk, sv;
-  long mreg = 1;
+  const TileOff vo = tile_voff(p.ld, tid);
   auto load_tile = [&](int kt) {
-    stage_load(sk, kbase, p.ld, kt * TK, n, tid);
-    stage_load(sv, vbase, p.ld, kt * TK, n, tid);
-    if (HAS_MASK && tid < TK) mreg = kt * TK + tid < n ? p.mask[tok0 + kt * TK + tid] : 0;   // keys past the end: masked
+    stage_load(sk, kbase, p.ld, kt * TK, n, vo);
+    stage_load(sv, vbase, p.ld, kt * TK, n, vo);
   };
   auto store_tile = [&](int buf) {
     char* base = lds + buf * STAGEB;
     stage_store(sk, base, tid);
     stage_store(sv, base + TILEB, tid);
-    if (HAS_MASK && tid < TK) ((float*)(base + 2 * TILEB))[tid] = mreg != 0 ? 0.f : NEG_MASK;
   };
   load_tile(0);   // (before the live bits are known)
-  uint64_t rem = live_finish<HAS_MASK>(lt, n, tid);
+  uint64_t rem = live_finish<HAS_MASK>(lt, p.mask, tok0, n, S, tid, kbias);
   // No unmasked key in the whole sequence: the reference's finfo.min absorbs every score and it attends uniformly, P = 1/S.
   // The forward gets there by the same absorption; its log-sum-exp (-2^100-sized) cannot carry log S, so the backward
   // kernels rebuild P from a zero score scale and lse = log S. (Never the case in a STonKGs batch - [CLS] is always live.)
@@ -552,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
   for (int it = 0;; ++it) {   // the live key tiles, in order (a fully masked tile gives dS = 0)
     const char* Ks = lds + (it & 1) * STAGEB;
     const char* Vs = Ks + TILEB;
-    const float* Mb = (const float*)(Ks + 2 * TILEB);
+    const float* Mb = kbias + kt * TK;   // (the sequence's key bias, written once by live_finish)
     const int nx = rem ? __builtin_ctzll(rem) : -1;
     rem &= rem - 1;
     if (nx >= 0) load_tile(nx);
@@ -675,15 +690,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
   const float* sptr = tid < TK ? p.lse + statbase + tid : p.delta + statbase + tid - TK;
   const float sfac = tid < TK ? -LOG2E : -inv_ds;
   const float nlog2s = -__builtin_amdgcn_logf((float)n);
+  const TileOff voq = tile_voff(p.ld, tid), vod = tile_voff(p.lddo, tid);
   auto load_tile = [&](int qt) {
-    stage_load(sq, qbase, p.ld, qt * TK, n, tid);
-    stage_load(sd, dbase, p.lddo, qt * TK, n, tid);
+    stage_load(sq, qbase, p.ld, qt * TK, n, voq);
+    stage_load(sd, dbase, p.lddo, qt * TK, n, vod);
     if (tid < 2 * TK) {
       slive = qt * TK + (tid & (TK - 1)) < nq;
       sreg = sptr[qt * TK];      // (inside the [B,NH,S] statistics arrays also past the sequence: S % 128 == 0)
     }
   };
-  // a query row past the sequence's end (its Q / dO are re-reads of the last row) gets -lse = NEG_MASK, which makes its
+  // a query row past the sequence's end (its Q / dO arrive as zeros) gets -lse = NEG_MASK, which makes its
   // P exactly zero for every key, and delta = 0: it adds nothing to dK and dV
   auto store_tile = [&](int buf) {
     char* base = lds + buf * STAGEB;
@@ -693,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
       ((float*)(base + 2 * TILEB))[tid] = !slive ? (tid < TK ? NEG_MASK : 0.f) : (uniform && tid < TK) ? nlog2s : sreg * sfac;
   };
   load_tile(0);   // (before the live bits are known; a workgroup that then leaves has asked for one tile in vain)
-  const uint64_t seq = live_finish<HAS_MASK>(lt, n, tid);
+  const uint64_t seq = live_finish<HAS_MASK>(lt, p.mask, tok0, n, S, tid, nullptr);
   uniform = seq == 0;
   const float sc2 = uniform ? 0.f : p.scale * LOG2E;
   bool wave_live = true, wg_live = true;
@@ -818,8 +834,9 @@ extern "C" int stonk_attention_fwd(const void* q, const void* k, const void* v, 
   const dim3 grid(S / 128, NH, B), block(256);
   hipStream_t st = (hipStream_t)stream;
   const bool hm = attention_mask != nullptr, dr = drop_p > 0.f;
-  if (hm && dr) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, block, 0, st, a);
-  else if (hm) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, block, 0, st, a);
+  const size_t kb = (size_t)S * sizeof(float);   // the sequence's key bias
+  if (hm && dr) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, block, kb, st, a);
+  else if (hm) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, block, kb, st, a);
   else if (dr) hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, block, 0, st, a);
   return stonk_launch_status();
@@ -853,7 +870,8 @@ static int attention_bwd_launch(int phases, const void* q, const void* k, const 
     hipLaunchKernelGGL(attn_delta_kernel, grid, dim3(128), 0, st, a);
 #define LAUNCH_BWD(HM, DR)                                                                                         \
   do {                                                                                                             \
-    if (phases & STONK_ATTN_BWD_DQ) hipLaunchKernelGGL((attn_bwd_dq_kernel<HM, DR>), grid, block, 0, st, a);       \
+    if (phases & STONK_ATTN_BWD_DQ)                                                                                \
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<HM, DR>), grid, block, HM ? (size_t)S * sizeof(float) : 0, st, a);    \
     if (phases & STONK_ATTN_BWD_DKV) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HM, DR>), grid, block, 0, st, a);     \
   } while (0)
   if (hm && dr) LAUNCH_BWD(true, true);

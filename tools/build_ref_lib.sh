@@ -5,7 +5,7 @@ set -e
 rev=${1:-HEAD}
 root=$(cd "$(dirname "$0")/.." && pwd)
 tmp=$(mktemp -d)
-git -C "$root" archive "$rev" stonkgs_amd/csrc include Makefile | tar -x -C "$tmp"
+git -C "$root" archive "$rev" stonkgs_amd/csrc include Makefile tools/gen_gemm_a4.py | tar -x -C "$tmp"
 make -C "$tmp" -j8 >/dev/null
 mkdir -p "$root/ab_ref"
 cp "$tmp/stonkgs_amd/csrc/libstonk_hip.so" "$root/ab_ref/libstonk_hip.so"

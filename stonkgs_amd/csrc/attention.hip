@@ -189,6 +189,9 @@ __device__ __forceinline__ TileOff tile_voff(long ld, int tid) {
 }
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 __device__ __forceinline__ void stage_load(Stage2& s, const bf16* base, long ld, int row0, int n, const TileOff& vo) {
+#ifdef STONK_ATTN_ABLATE_LOADS   // timing experiment (tools/attn_probe.py): every tile re-reads the sequence's first - cache hits
+  row0 = 0;
+#endif
   row0 = __builtin_amdgcn_readfirstlane(row0);
   const int rows = n - row0 < TK ? n - row0 : TK;   // >= 1: the caller only asks for tiles that start inside the sequence
   const __amdgpu_buffer_rsrc_t rs =
@@ -203,6 +206,12 @@ __device__ __forceinline__ void stage_store(const Stage2& s, char* tile, int tid
     *(bf16x8*)(tile + tile_off(id >> 3, (id & 7) * 8)) = s.c[i];
   }
 }
+
+#ifdef STONK_ATTN_ABLATE_BARRIER   // timing experiment: the waves of a workgroup run free (races: garbage results)
+#define TILE_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define TILE_BARRIER() __syncthreads()
+#endif
 
 // Every kernel below runs the same pipeline: tile t+1 is fetched into registers while tile t is computed from LDS
 // stage t&1, written to the other stage when the compute is done, ONE barrier per tile.
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnArgs p) {
         for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(tr_frag(Vs, sub * 32 + 16 * ks, dt * 32, lane), pf, o[dt]);
       }
     if (nx >= 0) store_tile((it + 1) & 1);
-    __syncthreads();
+    TILE_BARRIER();
     if (nx < 0) break;
     kt = nx;
   }
@@ -616,7 +625,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs p) {
       }
     }
     if (nx >= 0) store_tile((it + 1) & 1);
-    __syncthreads();
+    TILE_BARRIER();
     if (nx < 0) break;
     kt = nx;
   }
@@ -782,7 +791,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
       }
     }
     if (qt + 1 < ntiles) store_tile((qt + 1) & 1);
-    __syncthreads();
+    TILE_BARRIER();
   }
   const float fk = DROPOUT ? p.scale * p.drop_scale : p.scale;
   const float fv = DROPOUT ? p.drop_scale : 1.f;

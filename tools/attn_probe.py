@@ -2,7 +2,8 @@
 of 32..256 rows, 12 heads, dropout 0.1, every row's mask word set) - this build against another build of the library
 (ab_ref/libstonk_hip.so, tools/build_ref_lib.sh), launches interleaved; and the two builds' results against each other
 (with dropout off, where both must agree to rounding; with dropout on when SAME_MASK=1, i.e. the generator is unchanged).
-  python tools/attn_probe.py > gpurun_out/attn_probe.log"""
+  python tools/attn_probe.py > gpurun_out/attn_probe.log
+LIBS=name=path,... adds further builds to the timing (the ablation variants -DSTONK_ATTN_ABLATE_LOADS / _BARRIER)."""
 import ctypes as C
 import os
 import sys
@@ -18,8 +19,8 @@ H = NH * 64
 DELTA, DQ, DKV = 1, 2, 4
 
 
-def load_ref():
-    path = os.path.join(ROOT, "ab_ref", "libstonk_hip.so")
+def load_ref(path=None):
+    path = path or os.path.join(ROOT, "ab_ref", "libstonk_hip.so")
     if not os.path.exists(path):
         return None
     h = C.CDLL(path)
@@ -64,6 +65,10 @@ def main():
         assert rc == 0, rc
 
     libs = [("new", new)] + ([("ref", ref)] if ref is not None else [])
+    # further builds, timing only (ablation variants: LIBS=name=path,name=path)
+    for item in filter(None, os.environ.get("LIBS", "").split(",")):
+        name, _, path = item.partition("=")
+        libs.append((name, load_ref(os.path.join(ROOT, path))))
     bufs = {n: Bufs() for n, _ in libs}
     # agreement
     for p in (0.0, 0.1):

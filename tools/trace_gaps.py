@@ -49,3 +49,12 @@ perq = collections.Counter()
 for s, e, n, q in win:
     perq[q] += e - s
 print("kernel time per queue / stream (ms per step):", {q: round(v / steps / 1e6, 3) for q, v in perq.items()})
+# the framework's own small launches (fills, copies): which, how large, on which queue, after which kernel
+print("ATen / runtime launches in one step (queue, us, grid, previous kernel on that queue):")
+last_on_q = {}
+step_lo = ends[-2]
+for s, e, n, q in win:
+    if s >= step_lo and ("at::native" in n or "rocclr" in n):
+        r = next(r for r in rows if int(r["Start_Timestamp"]) == s and r["Kernel_Name"] == n)
+        print(f"  q{q} {(e - s) / 1e3:7.1f} us grid {r.get('Grid_Size', '?'):>10s}  {n[:60]:60s} after {last_on_q.get(q, '-')[:50]}")
+    last_on_q[q] = n

@@ -114,6 +114,12 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
   constexpr int NPB = BN_ / 32;       // 8-row pieces of the B image per wave and K tile
   constexpr int BROWS_W = BN_ / 4;    // rows of the B image each wave stages
   constexpr int NACC = 2 * NBJ;       // accumulator registers in units of 16
+  // The two decoder forms are compile-time variants: in the bf16 instances a work item is a whole tile and the output
+  // descriptor is loop-invariant, exactly as before they existed - a handful of further scalars alive across the K loop
+  // was enough to push every 256-wide instance into scratch (29-78 registers spilled, FFN-up 144 -> 175 us in the step).
+  constexpr int OUT = EPI & STONK_EPI_OUT_MASK;
+  constexpr bool SPLIT = OUT == STONK_EPI_OUT_F32_ATOMIC;   // work item = (tile, K share)
+  constexpr bool REBASE = OUT != STONK_EPI_OUT_BF16;        // output addressed from the tile's first row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -133,13 +139,13 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
   // workgroups would run as a second, mostly empty round (20 tiles x 13 shares on 256 CUs: 12 shares fill one round)
   const int nk_all = p.K / BK;        // even, >= 2 (launcher)
   const int tiles_mn = ntm * ntn;
-  int sk = p.split_k;
-  if (sk > 1 && tiles_mn > 0) {
+  int sk = SPLIT ? p.split_k : 1;
+  if (SPLIT && sk > 1 && tiles_mn > 0) {
     const int fit = gridDim.x / tiles_mn;
     sk = sk < fit ? sk : (fit > 1 ? fit : 1);
   }
-  const int per = sk > 1 ? ((nk_all + 2 * sk - 1) / (2 * sk)) * 2 : nk_all;
-  const int nsp = (nk_all + per - 1) / per;
+  const int per = (SPLIT && sk > 1) ? ((nk_all + 2 * sk - 1) / (2 * sk)) * 2 : nk_all;
+  const int nsp = SPLIT ? (nk_all + per - 1) / per : 1;
   const int total = tiles_mn * nsp;   // (the tiles of one K share are neighbours: they share operand panels in an XCD's L2)
   const int G = gridDim.x;
 
@@ -154,10 +160,14 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
       if (s >= q + (x < rem ? 1 : 0)) return false;
       idx = r * G + x * q + (x < rem ? x : rem) + s;
     }
-    const int sp = nsp > 1 ? idx / tiles_mn : 0;
-    idx -= sp * tiles_mn;
-    o.k0 = sp * per;
-    o.nk = nk_all - o.k0 < per ? nk_all - o.k0 : per;
+    o.k0 = 0;
+    o.nk = nk_all;
+    if (SPLIT && nsp > 1) {
+      const int sp = idx / tiles_mn;
+      idx -= sp * tiles_mn;
+      o.k0 = sp * per;
+      o.nk = nk_all - o.k0 < per ? nk_all - o.k0 : per;
+    }
     int rt, ct;
     if (ntm >= ntn) {
       rt = idx / ntn;
@@ -205,11 +215,17 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
 
   // (extents: the tile's own rows only - 256 x ld bytes always fits 32 bits, M x ld need not)
   auto cursor_of = [&](const Work& w, i32x4& a, i32x4& b) {
-    const unsigned long pa = (unsigned long)p.A + (unsigned long)((long)w.m0 * lda2) + (unsigned long)(w.k0 * (BK * 2));
-    const unsigned long pb = (unsigned long)p.B + (unsigned long)((long)w.n0 * ldb2) + (unsigned long)(w.k0 * (BK * 2));
-    const int ra = M - w.m0 < BM ? M - w.m0 : BM, rb = N - w.n0 < BN ? N - w.n0 : BN;
-    a = (i32x4){(int)(unsigned)pa, (int)((pa >> 32) & 0xffff), ra * lda2 - w.k0 * (BK * 2), 0x00020000};
-    b = (i32x4){(int)(unsigned)pb, (int)((pb >> 32) & 0xffff), rb * ldb2 - w.k0 * (BK * 2), 0x00020000};
+    const int kb = SPLIT ? w.k0 * (BK * 2) : 0;
+    const unsigned long pa = (unsigned long)p.A + (unsigned long)((long)w.m0 * lda2) + (unsigned long)kb;
+    const unsigned long pb = (unsigned long)p.B + (unsigned long)((long)w.n0 * ldb2) + (unsigned long)kb;
+    if (REBASE) {
+      const int ra = M - w.m0 < BM ? M - w.m0 : BM, rb = N - w.n0 < BN ? N - w.n0 : BN;
+      a = (i32x4){(int)(unsigned)pa, (int)((pa >> 32) & 0xffff), ra * lda2 - kb, 0x00020000};
+      b = (i32x4){(int)(unsigned)pb, (int)((pb >> 32) & 0xffff), rb * ldb2 - kb, 0x00020000};
+    } else {   // (bf16 launches: M x ld fits 32 bits - the launcher's condition)
+      a = (i32x4){(int)(unsigned)pa, (int)((pa >> 32) & 0xffff), (M - w.m0) * lda2, 0x00020000};
+      b = (i32x4){(int)(unsigned)pb, (int)((pb >> 32) & 0xffff), (N - w.n0) * ldb2, 0x00020000};
+    }
   };
 
   Work cw, nw;
@@ -230,12 +246,12 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
   else
     asm volatile(STONK_A4_PROLOGUE_192 : "+{s[36:39]}"(curA), "+{s[40:43]}"(curB) : STONK_A4_VOFF_OPERANDS : "m0", "scc", "memory");
 
-  constexpr int OUT = EPI & STONK_EPI_OUT_MASK;
   static_assert(OUT == STONK_EPI_OUT_BF16 || ((OUT == STONK_EPI_OUT_F16 || OUT == STONK_EPI_OUT_F32_ATOMIC) && (EPI & ~STONK_EPI_OUT_MASK) == 0),
                 "fp16 / atomic fp32 output: the plain product");
   constexpr int CB = OUT == STONK_EPI_OUT_F32_ATOMIC ? 4 : 2;   // bytes per output element
   const int flags = EPI & ~STONK_EPI_OUT_MASK;
   const int ldc_b = (int)p.ldc * CB, ldr_b = (int)p.ldr * 2, ldx_b = (int)p.ldaux * 2;
+  const __amdgpu_buffer_rsrc_t rC0 = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, REBASE ? 0 : M * ldc_b, 0x00020000);
   const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.resid, 0, M * ldr_b, 0x00020000);
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.aux, 0, M * ldx_b, 0x00020000);
   const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, N * 4, 0x00020000);
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
     i32x4 nxA, nxB;
     cursor_of(more ? nw : cw, nxA, nxB);   // (no next tile: the cursor re-reads this tile's first K tiles, never consumed)
     f32x16 acc[16];
-    int rem = cw.nk >> 1;
+    int rem = (SPLIT ? cw.nk : nk_all) >> 1;
     // the bias of this lane's columns: requested before the K loop, used after it
     f32x4 bq[NJP][2];
     if (flags & STONK_EPI_BIAS) {
@@ -304,7 +320,9 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
     // the output through a buffer that starts at the tile's first row and ends with its last one (M x ldc bytes need not
     // fit 32 bits: 16 384 rows of 175 104 logits)
     const int crows = M - cw.m0 < BM ? M - cw.m0 : BM;
-    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((char*)p.C + (long)cw.m0 * ldc_b, 0, crows * ldc_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rC =
+        REBASE ? __builtin_amdgcn_make_buffer_rsrc((char*)p.C + (long)cw.m0 * ldc_b, 0, crows * ldc_b, 0x00020000) : rC0;
+    const int cm0 = REBASE ? cw.m0 : 0;   // row the output offsets count from
     bf16x8 sd[NJP];
     auto side_request = [&](const int i) {
       if (!SIDE) return;
@@ -391,7 +409,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a4_kernel(const GemmArgs p) {
         so.aux = so.res = cur[jp];
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         epilogue8_pre(v, p, rest & ~STONK_EPI_SAVE_PREACT, m, n, z4, z4, so);
-        const int co = (m - cw.m0) * ldc_b + n * CB + oob;
+        const int co = (m - cm0) * ldc_b + n * CB + oob;
         if (OUT == STONK_EPI_OUT_F32_ATOMIC) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v[e] * p.alpha, rC, co + 4 * e, 0, 0);
@@ -459,8 +477,8 @@ int stonk_gemm_a4_launch(const GemmArgs& a, int tile_n, int items_per_wg, hipStr
   const long tiles = (tile_n == 192 ? ntm * (a.N / 192) : ntm * ((a.N + 255) / 256)) * nsp;
   const int grid = (int)(items_per_wg > 0 ? (tiles + items_per_wg - 1) / items_per_wg : (tiles < n_cu ? tiles : n_cu));
   if (out == STONK_EPI_OUT_F16) return launch_a4<STONK_EPI_OUT_F16, 256>(a, grid, st);
-  if (out == STONK_EPI_OUT_F32_ATOMIC)
-    return tile_n == 192 ? launch_a4<STONK_EPI_OUT_F32_ATOMIC, 192>(a, grid, st) : launch_a4<STONK_EPI_OUT_F32_ATOMIC, 256>(a, grid, st);
+  // (the atomic form on 256 x 192 tiles only: its 256-wide instance does not fit the compiler's half of the register file)
+  if (out == STONK_EPI_OUT_F32_ATOMIC) return tile_n == 192 ? launch_a4<STONK_EPI_OUT_F32_ATOMIC, 192>(a, grid, st) : STONK_ESHAPE;
   if (tile_n == 192) {
     switch (epi) {
       case 0: return launch_a4<0, 192>(a, grid, st);

@@ -428,3 +428,27 @@ def test_asan_host_build_of_the_launchers():
                            timeout=600)
     assert child.returncode == 0 and "2 passed" in child.stdout, child.stdout[-2000:] + child.stderr[-2000:]
     assert "AddressSanitizer" not in child.stderr
+
+
+def test_written_out_kernels_use_no_scratch():
+    """The hand-laid-out register files of the written-out GEMM kernels and the attention kernels must not spill: a spill
+    keeps every result right and costs 10-20 % of a launch (round 4: a few more scalars alive across the K loop put every
+    256-wide gemm_a4 instance into scratch). Read from the built objects' code-object metadata (tools/kernel_resources.py);
+    the weight-gradient kernel's 272 bytes (reloaded once per work item, outside the loop) are its known state."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    csrc = os.path.join(root, "stonkgs_amd", "csrc")
+    a4 = kr.kernel_resources(os.path.join(csrc, "gemm_a4.o"))
+    assert len(a4) >= 17 and all("gemm_a4_kernel" in k["name"] for k in a4)
+    bad = [(k["name"], k["scratch"]) for k in a4 if k["scratch"] or k.get("vgpr_spill", 0)]
+    assert not bad, bad
+    tn = kr.kernel_resources(os.path.join(csrc, "gemm_tn_a4.o"))
+    assert [k["scratch"] <= 272 for k in tn] == [True]
+    attn = kr.kernel_resources(os.path.join(csrc, "attention.o"))
+    bad = [(k["name"], k["scratch"]) for k in attn if k["scratch"] or k.get("vgpr_spill", 0)]
+    assert len(attn) == 13 and not bad, bad

@@ -56,7 +56,7 @@ def main():
                       lambda: gemm(hs, W, logits, CAP, npad, H, hip.EPI_OUT_F16, 1, m_dev, 0)])
         print(f"{name:7s} forward  {cnt} x {npad} x {H} ({gflop:.0f} GFLOP, {cnt * npad * 2 / 1e6:.0f} MB of fp16 logits): "
               + "  ".join(f"{n} {m:7.1f} us ({gflop / m * 1e-3:.2f} PF/s, min {mn:.1f})" for n, (m, mn) in zip(("wave8", "a4_256", "auto"), fwd)), flush=True)
-        variants = [("wave8/8", WAVE8, 8), ("a4_192/64", ASM4_192, 64), ("a4_256/64", ASM4, 64), ("a4_192/8", ASM4_192, 8)]
+        variants = [("wave8/8", WAVE8, 8), ("a4_192/64", ASM4_192, 64), ("a4_192/8", ASM4_192, 8)]
         bwd = timeit([(lambda k=k, s=s: gemm(dl, Wt, dhs, CAP, H, npad, hip.EPI_OUT_F32_ATOMIC, s, m_dev, k)) for _, k, s in variants])
         print(f"{name:7s} dgrad    {cnt} x {H} x {npad}: "
               + "  ".join(f"{n} {m:7.1f} us ({gflop / m * 1e-3:.2f} PF/s, min {mn:.1f})" for (n, _, _), (m, mn) in zip(variants, bwd)), flush=True)

@@ -93,6 +93,10 @@ class Engine:
         # prefetch; measured on one GPU with nothing beside it (tools/ab_step.py dispatched_pairs engine.comm_overlap=1)
         self.dispatched_pairs = True
         self.decoder_dgrad_256 = True
+        # weight gradients whose row count is a multiple of 128 only (the text decoder's 29 056 = 113.5 x 256) on the
+        # written-out 256x256 kernel as well (its last row tile is half empty, the buffers' range checks drop what it
+        # adds): correct, and no change to the step - 26.76 against 26.77 ms interleaved (tools/ab_step.py tn_ragged) - so off
+        self.tn_ragged = False
         # the label-sparse decoders' dgrad on gemm_a4.hip (fp32 atomics over a K split): measured SLOWER than the eight-wave
         # kernel at these shapes - rows 58 / 350 KB apart, 737 against 612 us (entity) and 349 against 148 (text),
         # tools/decoder_probe.py - so off; the decoders' FORWARD (fp16 logits) does run there: 687 against 888, 128 / 168
@@ -275,7 +279,8 @@ class Engine:
         # stream) the kernel is held to 160 CUs' worth of workgroups (split_k = -160): another -1.5 ms
         # ... and so does the entity decoder's 175 104 x 768 gradient (2052 unsplit tiles, device-side token count, 5.7 GB
         # operand extent - the kernel re-bases its buffer resources per K tile): 863 us against 966 alone, -0.27 ms in the step
-        if tiles >= self.tn_min_tiles and K >= self.tn_min_k and M % 256 == 0 and N % 256 == 0 and not self.tn_v1:
+        if (tiles >= self.tn_min_tiles and K >= self.tn_min_k and (M % 256 == 0 or self.tn_ragged) and N % 256 == 0
+                and not self.tn_v1):
             if side_stream and self.tn_cus_small and tiles < 64:   # (tiles counts 128x128 ones: 64 = 16 of 256x256)
                 return -self.tn_cus_small
             return -self.tn_cus if side_stream else 0

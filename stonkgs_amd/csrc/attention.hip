@@ -745,11 +745,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
         s[i] = mb;
         dp[i] = 0.f;
       }
+      // LDS operands are requested a phase ahead of the MFMAs that use them, and the scheduler is told to leave them
+      // there: left alone it sinks every read next to its MFMA (fewer live registers) and each of the tile's 32 MFMAs
+      // then waits out an LDS round trip - with two waves per SIMD nobody hides that (the loop was load / wait / MFMA).
+      bf16x8 qa[4], da[4];
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
-        s = mfma32(row_frag(Qs, sub * 32, st, r, hh), kf[st], s);    // S[q][k] (+ key bias)
-        dp = mfma32(row_frag(Ds, sub * 32, st, r, hh), vf[st], dp);  // dP[q][k] = sum_d dO[q][d] V[k][d]
+        qa[st] = row_frag(Qs, sub * 32, st, r, hh);
+        da[st] = row_frag(Ds, sub * 32, st, r, hh);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        s = mfma32(qa[st], kf[st], s);    // S[q][k] (+ key bias)
+        dp = mfma32(da[st], vf[st], dp);  // dP[q][k] = sum_d dO[q][d] V[k][d]
+      }
+      // the transposed operands of dV^T / dK^T: requested now, used after the softmax arithmetic below
+      bf16x8 td[2][2], tq[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          td[ks][dt] = tr_frag(Ds, sub * 32 + 16 * ks, dt * 32, lane);
+          tq[ks][dt] = tr_frag(Qs, sub * 32 + 16 * ks, dt * 32, lane);
+        }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 nls = *(const f32x4*)(Ls + sub * 32 + 8 * g + 4 * hh);
@@ -785,8 +805,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs p) 
         const bf16x8 pf = pack8(e), dsf = pack8(f);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          dv[dt] = mfma32(tr_frag(Ds, sub * 32 + 16 * ks, dt * 32, lane), pf, dv[dt]);   // dV^T += dO^T . P
-          dk[dt] = mfma32(tr_frag(Qs, sub * 32 + 16 * ks, dt * 32, lane), dsf, dk[dt]);  // dK^T += Q^T . dS
+          dv[dt] = mfma32(td[ks][dt], pf, dv[dt]);   // dV^T += dO^T . P
+          dk[dt] = mfma32(tq[ks][dt], dsf, dk[dt]);  // dK^T += Q^T . dS
         }
       }
     }

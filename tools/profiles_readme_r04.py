@@ -1,0 +1,116 @@
+"""Writes the round-4 section of profiles/README.md from the artifacts in profiles/ (everything above the round-3 heading is
+replaced).  python tools/profiles_readme_r04.py"""
+import csv
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+
+
+def last_json(name):
+    return json.loads([l for l in open(os.path.join(P, name)) if l.startswith("{")][-1])
+
+
+d = last_json("r04_final_bench.json")
+u = last_json("r04_bench_under_rocprof.json")
+c4 = last_json("r04_c4_24L1024_bench.json")
+rows = list(csv.DictReader(open(os.path.join(P, "r04_kernel_stats.csv"))))
+steps = 9
+
+
+def ms(pred):
+    return sum(float(r["TotalDurationNs"]) for r in rows if pred(r["Name"])) / steps / 1e6
+
+
+def avg_us(sub):
+    r = next(r for r in rows if sub in r["Name"])
+    return float(r["AverageNs"]) / 1e3
+
+
+tn = next(r for r in rows if "gemm_tn_a4" in r["Name"])
+tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
+a4 = ms(lambda n: "gemm_a4_kernel" in n)
+att = ms(lambda n: "attn_" in n)
+ln = ms(lambda n: "layernorm" in n or "ln_partial" in n)
+opt = ms(lambda n: "adamw" in n or "sumsq" in n or "transpose_batched" in n)
+dec = ms(lambda n: "gemm256_kernel" in n or "softmax_xent" in n or "gemm_tn_kernel" in n)
+n_a4 = sum(1 for r in rows if "gemm_a4_kernel" in r["Name"])
+sq = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(P, "r04_pmc_mfma.csv")))}
+tr = {r[list(r)[0]]: r for r in csv.DictReader(open(os.path.join(P, "r04_pmc_traffic.csv")))}
+tnsq = sq["gemm_tn_a4_kernel"]
+ab = [l.split() for l in open(os.path.join(P, "r04_ab_libs.log")) if l.split() and l.split()[0] in ("ref", "new")]
+ab_ref = sorted(float(x[1]) for x in ab if x[0] == "ref")
+ab_new = sorted(float(x[1]) for x in ab if x[0] == "new")
+rf = d["roofline"]
+fwd_us, dq_us, dkv_us = avg_us("attn_fwd_kernel<true, true>"), avg_us("attn_bwd_dq_kernel<true, true>"), avg_us("attn_bwd_dkv_kernel<true, true>")
+attn_sq = {k: sq[f'void {k}<true, true>'] for k in ("attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel")}
+
+text = f"""# profiles — round 4 (MI355X, gfx950, ROCm 7.2, one GPU)
+
+Everything below was taken on the round's FINAL code (one `gpurun` call, one box) unless a row says otherwise.
+
+| file | what | command |
+|---|---|---|
+| `r04_final_bench.json` | the bench line as the driver runs it (20 steps, 5 warm-up, CPU baseline on) | `python bench.py` |
+| `r04_kernel_stats.csv`, `r04_bench_under_rocprof.json` | rocprofv3 per-kernel summary of the bench (9 steps: 2 warm-up + 5 timed + 2 instrumented) and the line it printed | `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline` (`tools/final_profiles.sh`) |
+| `r04_pmc_traffic.csv` | per-kernel bytes at the L2's memory side (two passes, condensed by `tools/summarize_pmc.py`) | `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline`, then `--pmc WRITE_SIZE` (`tools/final_pmc.sh`) |
+| `r04_pmc_mfma.csv` | per-kernel SQ counters (matrix-pipe utilisation; share of wave time parked at waits / ready but not issued / issuing VALU / LDS; `tools/summarize_pmc_sq.py`) | third pass of `tools/final_pmc.sh` |
+| `r04_ab_libs.log` | the library of the round's first profile commit (3fa1a35) against the final one, the bench alternating between them in one call: what the second half of the round bought | `tools/build_ref_lib.sh 3fa1a35; bash tools/ab_libs.sh 3 40` |
+| `r04_a4_probe.log` | the NT launches of the step ALONE at 26 432 rows with their real epilogues, interleaved: compiled four-wave kernel (256- / 192-wide tiles), written-out kernel (same), `AUTO`, vendor library where the launch is plain (taken at commit 3fa1a35; the bf16 instances are unchanged since) | `python tools/a4_probe.py time` |
+| `r04_tn_probe.log` | the four weight gradients of a layer: parity, then written-out against compiled kernel, on all CUs and held to 160 (commit 3fa1a35; kernel unchanged since) | `python tools/tn_probe.py` |
+| `r04_decoder_probe.log` | the label-sparse decoders' forward (fp16 logits) and dgrad (fp32 atomics over a K split) alone at the bench's sizes: eight-wave kernel against the written-out one | `python tools/decoder_probe.py` |
+| `r04_attn_probe.log` | the three attention kernels alone in the step's packed form, final code against commit 3fa1a35, interleaved, results compared bit for bit | `tools/build_ref_lib.sh 3fa1a35; SAME_MASK=1 python tools/attn_probe.py` |
+| `r04_attn_ablations.log` | the same kernels without their global loads' latency, without the per-tile barrier, without both (timing only): what the waits are NOT made of | `LIBS=... python tools/attn_probe.py` with `-DSTONK_ATTN_ABLATE_LOADS / _BARRIER` builds |
+| `r04_a4_sweep.md` | schedule variants and ablations of the written-out GEMM loop (where its cycles go: LDS-DMA issue) | `python tools/a4_sweep.py build` here, `run` on the box |
+| `r04_ab.md` | the step-level interleaved A/Bs of the round (optimizer-chain ideas, decoder kernels, a CU-share sweep) | `tools/ab_step.py`, `tools/sweep_engine_int.py`, `tools/adamw_ab.py` |
+| `r04_overlap_budget.md` | when each gradient bucket is final on this build's timeline and what a ring all-reduce would leave exposed at N = 2 / 4 / 8, for both bucket plans (commit 691598a; the backward timeline has since shortened by ~0.3 ms) | `python tools/overlap_budget.py` |
+| `r04_step_marks.log` | the step without a profiler: optimizer boundary and forward + backward spans | `python tools/step_marks.py` |
+| `r04_trace_gaps.txt` | union of all kernels' intervals over two steps: how long NO kernel runs, and the framework's own small launches | `bash tools/trace_gaps.sh` |
+| `r04_step_series.log`, `r04_bench_kw.log` | per-step GPU time of a 50-step run (settled from the second step on) and the bench repeated with different K / W on one box (run-to-run spread of one build on one box: 26.3 - 26.8 ms) | `python tools/step_series.py 50`, `bash tools/bench_kw.sh` |
+| `r04_parity_envelopes.log` | what the round's new parity tests print: HIP gradients against the reference's own bf16-autocast gradients (g16 / g17), the HIP loss curves against the reference's fp32 AND bf16 curves (g11 / g12) | `pytest tests/test_shape_true_gpu.py tests/test_losscurve_gpu.py -s -k "real_depth or config5_on_12 or envelope"` |
+| `r04_c4_24L1024_bench.json` | BASELINE config 4 (24L / 1024h / 16 heads / 4096, batch 64; commit 3fa1a35) | `python bench.py --model 24L1024 --steps 10 --warmup 3 --no-cpu-baseline` |
+
+## Headline (round 4)
+
+* **{d["value"]:.0f} text-triple pairs/s, {d["ms_per_step"]:.2f} ms per step** as the driver runs the bench (`r04_final_bench.json`; CPU oracle
+  {d["cpu_baseline"]["value"]:.2f} pairs/s on the box's {d["cpu_baseline"]["cores"]} threads); {u["value"]:.0f} / {u["ms_per_step"]:.2f} ms under rocprofv3. Round 3's driver run: 2 231 / 28.69.
+  One build on one box reads 26.3 - 26.8 ms from process to process (`r04_bench_kw.log`) and boxes differ by another 2-3 %, so
+  the round's changes were judged by interleaved A/Bs only; the last one, `r04_ab_libs.log`: {ab_ref[len(ab_ref) // 2]:.2f} ms with the library of the
+  round's first profile commit, **{ab_new[len(ab_new) // 2]:.2f} ms** with the final one (the same call, alternating).
+* What changed, first half of the round: **every bf16 GEMM of the step runs on a loop that is written out instruction by
+  instruction** (`gemm_a4.hip`, `gemm_tn_a4.hip`; DESIGN 4.3). Alone the NT launches beat the vendor library on the step's four
+  shapes (`r04_a4_probe.log`: FFN-up 107 us against 128, FFN-down 96 / 103, QKV 81 / 89, 768x768 33 / 39) and the compiled four-wave
+  kernel by 10-25 % with the real epilogues; the weight gradient is 15-20 % faster than its compiled form (`r04_tn_probe.log`).
+  Second half (-0.4 ms, `r04_ab_libs.log`): the decoders' forward on that kernel (entity logits 892 -> 600 us alone,
+  `r04_decoder_probe.log`), attention tile loads through scalar-built buffer descriptors and the key-mask bias in LDS once
+  per sequence (forward 96 -> 90 us, dQ 115 -> 110), the dK/dV kernel's LDS operands requested a phase ahead of their MFMAs
+  (151 -> 140; all three bit-identical, `r04_attn_probe.log`).
+* `roofline` (dominant kernel `gemm_tn_a4_kernel`, {rf["launches_per_step"]} launches per step, {rf["avg_launch_gflop"]:.1f} GFLOP each): **{rf["frac"]:.3f} of the 2.5 PFLOP/s peak as the
+  step runs it** ({rf["avg_launch_us"]:.1f} us per launch by HIP events on the second stream; rocprofv3 average of the same kernel: {float(tn["AverageNs"]) / 1e3:.1f} us ->
+  {rf["avg_launch_gflop"] / (float(tn["AverageNs"]) / 1e3) / 2500 * 1e3:.3f}; round 3: 0.169 at 250 us). In the step the kernel is HELD to 160 of the 256 CUs beside the dgrad chain; on
+  those CUs alone it runs FFN-up in 143 us = 0.35 of the whole chip's peak = 0.56 of its share's (`r04_tn_probe.log`).
+  Matrix-pipe utilisation {float(tnsq["mfma_pipe_utilisation"]):.2f} (`r04_pmc_mfma.csv`; round 3: 0.27). Traffic per launch (`r04_pmc_traffic.csv`): 250.0 MB fetched
+  (FETCH_SIZE doubled) + 60.0 MB of float atomics = 310 MB against 193.5 algorithmic = 1.60x - unchanged (four K splits
+  through the fabric's atomics).
+* `by_kernel.nt` {rf["by_kernel"]["nt"]["frac"]:.3f} ({rf["by_kernel"]["nt"]["ms_per_step"]:.1f} ms of launches; round 3: 0.276 / 18.6), `all_gemm` {d["all_gemm"]["frac"]:.3f} (0.234), `encoder_path`
+  {d["encoder_path"]["frac"]:.3f} (0.266), `step_mfma_frac` {d["step_mfma_frac"]:.3f} (0.267). Config 4 (commit 3fa1a35): {c4["value"]:.0f} pairs/s, {c4["ms_per_step"]:.1f} ms,
+  `step_mfma_frac` {c4["step_mfma_frac"]:.3f} (round 3: 781 / 81.9 / 0.308).
+* Where the {tot:.1f} ms of kernel time per profiled step go (`r04_kernel_stats.csv`): written-out NT kernel {a4:.1f} ({n_a4} epilogue
+  instances, the decoders' fp16 logits among them), weight gradient {float(tn["TotalDurationNs"]) / steps / 1e6:.1f}, attention {att:.1f} (forward {fwd_us:.0f} + dQ {dq_us:.0f} + dK/dV {dkv_us:.0f} us per layer in the step), LayerNorm {ln:.1f},
+  optimizer chain {opt:.1f}, the decoders' dgrad on the eight-wave kernel, the small weight gradients and the cross-entropy {dec:.1f}. The GPU is never idle: some kernel runs
+  for all but 0.14 ms of a step (`r04_trace_gaps.txt`), the step settles in its second iteration (`r04_step_series.log`).
+* Attention's counters after the round (`r04_pmc_mfma.csv`; round 3 in brackets): share of wave time parked at waits -
+  forward {float(attn_sq["attn_fwd_kernel"]["wait_any_over_wave_cycles"]):.2f} (0.32), dQ {float(attn_sq["attn_bwd_dq_kernel"]["wait_any_over_wave_cycles"]):.2f} (0.32), dK/dV {float(attn_sq["attn_bwd_dkv_kernel"]["wait_any_over_wave_cycles"]):.2f} (0.38); matrix-pipe utilisation {float(attn_sq["attn_fwd_kernel"]["mfma_pipe_utilisation"]):.2f} / {float(attn_sq["attn_bwd_dq_kernel"]["mfma_pipe_utilisation"]):.2f} / {float(attn_sq["attn_bwd_dkv_kernel"]["mfma_pipe_utilisation"]):.2f}
+  (0.20 / 0.25 / 0.22). The ablations (`r04_attn_ablations.log`) say what the remaining waits are NOT: with every tile load a
+  cache hit AND no per-tile barrier the three kernels are 7 % faster, no more - the time is the wave's own instruction
+  stream (DESIGN 7).
+* SCALE: no multi-GPU box in this round either. What one GPU can say about the exchange is in `r04_overlap_budget.md`.
+
+"""
+path = os.path.join(P, "README.md")
+old = open(path).read()
+cut = old.index("# profiles — round 3")
+open(path, "w").write(text + old[cut:])
+print(text[:200])

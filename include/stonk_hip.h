@@ -36,9 +36,9 @@ int stonk_abi_version(void);
  * modifies the two users of `aux`: SAVE_PREACT (next to GELU) then stores gelu'(pre-activation) and GELU_BWD multiplies
  * by `aux` as is - the training step uses the pair, so the erf/exp of GELU' are evaluated once, in the forward epilogue.
  * m_dev / k_dev (nullable): effective M / K read from device memory at run time (label-sparse decoders).
- * `kernel`: STONK_GEMM_AUTO (the launcher picks one of its three kernels from shape and epilogue), an explicit
- * STONK_GEMM_TILE128 / _WAVE8 / _WAVE4 / _WAVE4_192 (an explicit kernel that cannot take the arguments is refused with
- * STONK_ESHAPE), or STONK_GEMM_DISPATCHED / _DISPATCHED2: AUTO's choice without a persistent grid (one / two work items per
+ * `kernel`: STONK_GEMM_AUTO (the launcher picks one of its kernels from shape and epilogue), an explicit
+ * STONK_GEMM_TILE128 / _WAVE8 / _WAVE4 / _WAVE4_192 / _ASM4 / _ASM4_192 (an explicit kernel that cannot take the arguments
+ * is refused with STONK_ESHAPE; stonk_flags.h says what each takes), or STONK_GEMM_DISPATCHED / _DISPATCHED2: AUTO's choice without a persistent grid (one / two work items per
  * workgroup), for launches that run while another stream - a collective - holds CUs.
  * Replaces torch addmm/mm of hf:models/bert/modeling_bert.py:154-156 (Q,K,V), :289-293 (attn out), :334-337
  * (FFN up + GELU), :347-351 (FFN down), :476-480 (head transform); ref:src/stonkgs/models/stonkgs_model.py:70-71

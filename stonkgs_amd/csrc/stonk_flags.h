@@ -32,8 +32,11 @@
                                  split waits for its last workgroup to get a CU */
 #define STONK_GEMM_DISPATCHED2 6 /* the same with TWO work items per workgroup (grid = tiles / 2): every second tile boundary                                  keeps its prefetch, the dispatcher still hands out the work in pieces far smaller than a                                  CU's share; where DISPATCHED runs 128x128 tiles this is DISPATCHED */
 #define STONK_GEMM_ASM4 7     /* persistent 256x256x64, four waves, 16x16x32 MFMAs, LDS-DMA operands, the K loop a written-out \
-                                 instruction stream (gemm_a4.hip): bf16 output, split_k == 1, the step's epilogues */
-#define STONK_GEMM_ASM4_192 8 /* the same on 256x192 tiles: N % 192 == 0, the epilogues of the N = 768 launches */
+                                 instruction stream (gemm_a4.hip): bf16 output (split_k == 1, the step's epilogues), or the \
+                                 plain product as fp16 (STONK_EPI_OUT_F16: the label-sparse logits; any M x ldc) */
+#define STONK_GEMM_ASM4_192 8 /* the same on 256x192 tiles: N % 192 == 0, the epilogues of the N = 768 launches; also the plain \
+                                 product added into fp32 by atomics (STONK_EPI_OUT_F32_ATOMIC, alpha as given) over a K split - \
+                                 there split_k is an UPPER bound: the kernel takes as many shares as fill its grid once */
 // --- stonk_layernorm_* `flags` ---
 #define STONK_LN_DROPOUT (1 << 0)
 // --- stonk_small_linear_* `act` ---

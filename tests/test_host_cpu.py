@@ -443,6 +443,11 @@ def test_written_out_kernels_use_no_scratch():
     kr = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(kr)
     csrc = os.path.join(root, "stonkgs_amd", "csrc")
+    import subprocess
+
+    # (objects are build products, not in the history: a no-op when __graft_entry__.build() has run)
+    r = subprocess.run(["make", "-C", root, "-j8"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
     a4 = kr.kernel_resources(os.path.join(csrc, "gemm_a4.o"))
     assert len(a4) >= 17 and all("gemm_a4_kernel" in k["name"] for k in a4)
     bad = [(k["name"], k["scratch"]) for k in a4 if k["scratch"] or k.get("vgpr_spill", 0)]

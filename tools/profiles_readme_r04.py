@@ -70,7 +70,7 @@ Everything below was taken on the round's FINAL code (one `gpurun` call, one box
 | `r04_trace_gaps.txt` | union of all kernels' intervals over two steps: how long NO kernel runs, and the framework's own small launches | `bash tools/trace_gaps.sh` |
 | `r04_step_series.log`, `r04_bench_kw.log` | per-step GPU time of a 50-step run (settled from the second step on) and the bench repeated with different K / W on one box (run-to-run spread of one build on one box: 26.3 - 26.8 ms) | `python tools/step_series.py 50`, `bash tools/bench_kw.sh` |
 | `r04_parity_envelopes.log` | what the round's new parity tests print: HIP gradients against the reference's own bf16-autocast gradients (g16 / g17), the HIP loss curves against the reference's fp32 AND bf16 curves (g11 / g12) | `pytest tests/test_shape_true_gpu.py tests/test_losscurve_gpu.py -s -k "real_depth or config5_on_12 or envelope"` |
-| `r04_c4_24L1024_bench.json` | BASELINE config 4 (24L / 1024h / 16 heads / 4096, batch 64; commit 3fa1a35) | `python bench.py --model 24L1024 --steps 10 --warmup 3 --no-cpu-baseline` |
+| `r04_c4_24L1024_bench.json` | BASELINE config 4 (24L / 1024h / 16 heads / 4096, batch 64) | `python bench.py --model 24L1024 --steps 10 --warmup 3 --no-cpu-baseline` |
 
 ## Headline (round 4)
 
@@ -95,7 +95,7 @@ Everything below was taken on the round's FINAL code (one `gpurun` call, one box
   (FETCH_SIZE doubled) + 60.0 MB of float atomics = 310 MB against 193.5 algorithmic = 1.60x - unchanged (four K splits
   through the fabric's atomics).
 * `by_kernel.nt` {rf["by_kernel"]["nt"]["frac"]:.3f} ({rf["by_kernel"]["nt"]["ms_per_step"]:.1f} ms of launches; round 3: 0.276 / 18.6), `all_gemm` {d["all_gemm"]["frac"]:.3f} (0.234), `encoder_path`
-  {d["encoder_path"]["frac"]:.3f} (0.266), `step_mfma_frac` {d["step_mfma_frac"]:.3f} (0.267). Config 4 (commit 3fa1a35): {c4["value"]:.0f} pairs/s, {c4["ms_per_step"]:.1f} ms,
+  {d["encoder_path"]["frac"]:.3f} (0.266), `step_mfma_frac` {d["step_mfma_frac"]:.3f} (0.267). Config 4: {c4["value"]:.0f} pairs/s, {c4["ms_per_step"]:.1f} ms,
   `step_mfma_frac` {c4["step_mfma_frac"]:.3f} (round 3: 781 / 81.9 / 0.308).
 * Where the {tot:.1f} ms of kernel time per profiled step go (`r04_kernel_stats.csv`): written-out NT kernel {a4:.1f} ({n_a4} epilogue
   instances, the decoders' fp16 logits among them), weight gradient {float(tn["TotalDurationNs"]) / steps / 1e6:.1f}, attention {att:.1f} (forward {fwd_us:.0f} + dQ {dq_us:.0f} + dK/dV {dkv_us:.0f} us per layer in the step), LayerNorm {ln:.1f},

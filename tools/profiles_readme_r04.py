@@ -58,14 +58,14 @@ Everything below was taken on the round's FINAL code (one `gpurun` call, one box
 | `r04_pmc_traffic.csv` | per-kernel bytes at the L2's memory side (two passes, condensed by `tools/summarize_pmc.py`) | `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline`, then `--pmc WRITE_SIZE` (`tools/final_pmc.sh`) |
 | `r04_pmc_mfma.csv` | per-kernel SQ counters (matrix-pipe utilisation; share of wave time parked at waits / ready but not issued / issuing VALU / LDS; `tools/summarize_pmc_sq.py`) | third pass of `tools/final_pmc.sh` |
 | `r04_ab_libs.log` | the library of the round's first profile commit (3fa1a35) against the final one, the bench alternating between them in one call: what the second half of the round bought | `tools/build_ref_lib.sh 3fa1a35; bash tools/ab_libs.sh 3 40` |
-| `r04_a4_probe.log` | the NT launches of the step ALONE at 26 432 rows with their real epilogues, interleaved: compiled four-wave kernel (256- / 192-wide tiles), written-out kernel (same), `AUTO`, vendor library where the launch is plain (taken at commit 3fa1a35; the bf16 instances are unchanged since) | `python tools/a4_probe.py time` |
-| `r04_tn_probe.log` | the four weight gradients of a layer: parity, then written-out against compiled kernel, on all CUs and held to 160 (commit 3fa1a35; kernel unchanged since) | `python tools/tn_probe.py` |
+| `r04_a4_probe.log` | the NT launches of the step ALONE at 26 432 rows with their real epilogues, interleaved: compiled four-wave kernel (256- / 192-wide tiles), written-out kernel (same), `AUTO`, vendor library where the launch is plain | `python tools/a4_probe.py time` |
+| `r04_tn_probe.log` | the four weight gradients of a layer: parity, then written-out against compiled kernel, on all CUs and held to 160 | `python tools/tn_probe.py` |
 | `r04_decoder_probe.log` | the label-sparse decoders' forward (fp16 logits) and dgrad (fp32 atomics over a K split) alone at the bench's sizes: eight-wave kernel against the written-out one | `python tools/decoder_probe.py` |
 | `r04_attn_probe.log` | the three attention kernels alone in the step's packed form, final code against commit 3fa1a35, interleaved, results compared bit for bit | `tools/build_ref_lib.sh 3fa1a35; SAME_MASK=1 python tools/attn_probe.py` |
 | `r04_attn_ablations.log` | the same kernels without their global loads' latency, without the per-tile barrier, without both (timing only): what the waits are NOT made of | `LIBS=... python tools/attn_probe.py` with `-DSTONK_ATTN_ABLATE_LOADS / _BARRIER` builds |
 | `r04_a4_sweep.md` | schedule variants and ablations of the written-out GEMM loop (where its cycles go: LDS-DMA issue) | `python tools/a4_sweep.py build` here, `run` on the box |
 | `r04_ab.md` | the step-level interleaved A/Bs of the round (optimizer-chain ideas, decoder kernels, a CU-share sweep) | `tools/ab_step.py`, `tools/sweep_engine_int.py`, `tools/adamw_ab.py` |
-| `r04_overlap_budget.md` | when each gradient bucket is final on this build's timeline and what a ring all-reduce would leave exposed at N = 2 / 4 / 8, for both bucket plans (commit 691598a; the backward timeline has since shortened by ~0.3 ms) | `python tools/overlap_budget.py` |
+| `r04_overlap_budget.md` | when each gradient bucket is final on this build's timeline and what a ring all-reduce would leave exposed at N = 2 / 4 / 8, for both bucket plans | `python tools/overlap_budget.py` |
 | `r04_step_marks.log` | the step without a profiler: optimizer boundary and forward + backward spans | `python tools/step_marks.py` |
 | `r04_trace_gaps.txt` | union of all kernels' intervals over two steps: how long NO kernel runs, and the framework's own small launches | `bash tools/trace_gaps.sh` |
 | `r04_step_series.log`, `r04_bench_kw.log` | per-step GPU time of a 50-step run (settled from the second step on) and the bench repeated with different K / W on one box (run-to-run spread of one build on one box: 26.3 - 26.8 ms) | `python tools/step_series.py 50`, `bash tools/bench_kw.sh` |

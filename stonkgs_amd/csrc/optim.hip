@@ -16,7 +16,12 @@ namespace {
 // drifted apart by an ulp per step (found with tools/dp_check.py). Slots and ticket live in a CALLER workspace
 // (stonk_sumsq_workspace_floats(): SUMSQ_MAX_BLOCKS slots + the ticket word, zeroed once by the caller; the kernel
 // leaves the ticket at zero), so launches on different streams with different workspaces do not meet.
-constexpr int SUMSQ_MAX_BLOCKS = 1024;
+// Grid cap = number of partial-sum slots. Fewer, longer-running workgroups stream better: alone on 974 MB (tools/sumsq_probe.py,
+// us) 256 blocks 181, 384: 179, 512: 193, 768: 213, 1024: 279 (3.5 TB/s - the round-3 value), 2048: 376, 4096: 569.
+#ifndef STONK_SUMSQ_BLOCKS
+#define STONK_SUMSQ_BLOCKS 256
+#endif
+constexpr int SUMSQ_MAX_BLOCKS = STONK_SUMSQ_BLOCKS;
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out,
                                                     float* __restrict__ g_sumsq_part, unsigned* __restrict__ ticket) {
@@ -77,6 +82,14 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 #endif
 #ifndef STONK_ADAMW_NT
 #define STONK_ADAMW_NT 0
+#endif
+#ifndef STONK_ADAMW_BLOCKS
+// grid cap. Alone on 243 M elements (ADAMW_AB=blocks tools/adamw_ab.py, us): 256 blocks 1516, 512: 1588, 1024: 1715, 4096: 1735 -
+// but IN THE STEP 256 blocks cost +1.6 ms (27.9-28.4 against 26.3-26.7 ms, tools/ab_libs.sh): the kernel runs on the optimizer
+// stream beside the next step's first launches, and 256 long-lived workgroups are placed once, on whatever CUs are free at
+// that moment, where 4096 short ones follow the CUs as they come free. (The gradient-norm pass before it does gain from
+// its 256 blocks in the step: -0.15 ms.)
+#define STONK_ADAMW_BLOCKS 4096
 #endif
 template <typename T>
 __device__ __forceinline__ T stream_load(const T* q) {
@@ -343,7 +356,7 @@ extern "C" int stonk_adamw_step(float* p, float* g, float* m, float* v, void* p_
   STONK_CHECK_ARG(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, STONK_EALIGN);
   STONK_CHECK_ARG(bias_corr1 > 0.f && bias_corr2 > 0.f, STONK_EINVAL);
   if (n == 0) return STONK_OK;
-  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16,
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n) < STONK_ADAMW_BLOCKS ? ew_grid(n) : STONK_ADAMW_BLOCKS), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)p_bf16,
                      (long)n, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, gnorm_sq_dev, max_grad_norm,
                      grad_scale, (const long*)decay_spans, n_spans, (long)span_base);
   return stonk_launch_status();

@@ -106,6 +106,9 @@ __global__ __launch_bounds__(256) void scatter_rows_f32_kernel(const float* __re
 // One block per labelled row: online (max, sum-exp) sweep of the logits (fp32, or the fp16 the decoder GEMM can leave:
 // LT), then a second sweep writes dlogits = (softmax - onehot) * gscale / count as bf16 (columns [ncols, npad) = 0).
 // loss_sum += lse - x[target]. All arithmetic in fp32. HBM-bound: 10 bytes per logit with fp32 logits, 6 with fp16.
+#ifndef STONK_XENT_BLOCKS
+#define STONK_XENT_BLOCKS 2048   // workgroups, one labelled row at a time each; alone at 2 432 rows x 175 104 (tools/bench_xent.py, us): 256: 942, 512: 714, 1024: 547, 2048: 529
+#endif
 template <typename LT> struct LogitVec;
 template <> struct LogitVec<float> {
   static __device__ __forceinline__ void load8(const float* x, float (&v)[8]) {
@@ -345,7 +348,7 @@ extern "C" int stonk_softmax_xent_fwd_bwd(const float* logits, int64_t ld, int n
   STONK_CHECK_ARG(logits && targets && count_dev && loss_sum && err_flag && cap_rows >= 0, STONK_EINVAL);
   STONK_CHECK_ARG(ncols > 0 && npad >= ncols && npad % 8 == 0 && ld >= npad && ld % 4 == 0, STONK_ESHAPE);
   STONK_CHECK_ARG(!dlogits || (ld_d >= npad && ld_d % 8 == 0), STONK_ESHAPE);
-  hipLaunchKernelGGL(softmax_xent_kernel<float>, dim3(2048), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, ncols,
+  hipLaunchKernelGGL(softmax_xent_kernel<float>, dim3(STONK_XENT_BLOCKS), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, ncols,
                      npad, targets, count_dev, loss_sum, (bf16*)dlogits, (long)ld_d, grad_scale, err_flag, cap_rows);
   return stonk_launch_status();
 }
@@ -357,7 +360,7 @@ extern "C" int stonk_softmax_xent_f16_fwd_bwd(const void* logits_f16, int64_t ld
   STONK_CHECK_ARG(ncols > 0 && npad >= ncols && npad % 8 == 0 && ld >= npad && ld % 8 == 0, STONK_ESHAPE);
   STONK_CHECK_ARG(!dlogits || (ld_d >= npad && ld_d % 8 == 0), STONK_ESHAPE);
   STONK_CHECK_ARG((uintptr_t)logits_f16 % 16 == 0, STONK_EALIGN);
-  hipLaunchKernelGGL(softmax_xent_kernel<_Float16>, dim3(2048), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(softmax_xent_kernel<_Float16>, dim3(STONK_XENT_BLOCKS), dim3(256), 0, (hipStream_t)stream,
                      (const _Float16*)logits_f16, (long)ld, ncols, npad, targets, count_dev, loss_sum, (bf16*)dlogits,
                      (long)ld_d, grad_scale, err_flag, cap_rows);
   return stonk_launch_status();

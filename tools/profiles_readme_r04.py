@@ -83,10 +83,11 @@ Everything below was taken on the round's FINAL code (one `gpurun` call, one box
   instruction** (`gemm_a4.hip`, `gemm_tn_a4.hip`; DESIGN 4.3). Alone the NT launches beat the vendor library on the step's four
   shapes (`r04_a4_probe.log`: FFN-up 107 us against 128, FFN-down 96 / 103, QKV 81 / 89, 768x768 33 / 39) and the compiled four-wave
   kernel by 10-25 % with the real epilogues; the weight gradient is 15-20 % faster than its compiled form (`r04_tn_probe.log`).
-  Second half (-0.4 ms, `r04_ab_libs.log`): the decoders' forward on that kernel (entity logits 892 -> 600 us alone,
+  Second half (-0.7 ms, `r04_ab_libs.log`): the decoders' forward on that kernel (entity logits 892 -> 600 us alone,
   `r04_decoder_probe.log`), attention tile loads through scalar-built buffer descriptors and the key-mask bias in LDS once
   per sequence (forward 96 -> 90 us, dQ 115 -> 110), the dK/dV kernel's LDS operands requested a phase ahead of their MFMAs
-  (151 -> 140; all three bit-identical, `r04_attn_probe.log`).
+  (151 -> 140; all three bit-identical, `r04_attn_probe.log`), the gradient-norm pass on 256 workgroups instead of 1024
+  (279 -> 181 us, `r04_sumsq_probe.log`).
 * `roofline` (dominant kernel `gemm_tn_a4_kernel`, {rf["launches_per_step"]} launches per step, {rf["avg_launch_gflop"]:.1f} GFLOP each): **{rf["frac"]:.3f} of the 2.5 PFLOP/s peak as the
   step runs it** ({rf["avg_launch_us"]:.1f} us per launch by HIP events on the second stream; rocprofv3 average of the same kernel: {float(tn["AverageNs"]) / 1e3:.1f} us ->
   {rf["avg_launch_gflop"] / (float(tn["AverageNs"]) / 1e3) / 2500 * 1e3:.3f}; round 3: 0.169 at 250 us). In the step the kernel is HELD to 160 of the 256 CUs beside the dgrad chain; on

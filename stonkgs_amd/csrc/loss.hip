@@ -11,42 +11,67 @@
 
 namespace {
 
-// Stable compaction of labels != -100 (single block scan; n = B * half is a few 10^4 at most).
+// Stable compaction of labels != -100 (one block; n = B * half is a few 10^4 at most).
 // rows_out[i] = token row (b*S + offset + pos) of the i-th labelled position, targets_out[i] = its label.
+// In chunks of 16 384 labels: sixteen COALESCED loads per thread requested at once (label j * 1024 + t), their ballots to
+// LDS, one exclusive scan over the 256 ballot words' popcounts, then every thread writes its labelled ones - three barriers
+// per chunk. (The first version walked the labels 1024 at a time with three barriers and a dependent global load per round:
+// 32 us for 16 384 labels, twice per step; a contiguous run per thread, uncoalesced: 21 us.)
 __global__ __launch_bounds__(1024) void label_compact_kernel(const long* __restrict__ labels, long n, int half, int S,
                                                              int offset, int* __restrict__ rows_out,
                                                              int* __restrict__ targets_out, int* __restrict__ count_out,
                                                              const int* __restrict__ row_of_pos) {
-  __shared__ int wsum[16];
-  __shared__ int base;
+  constexpr int R = 16;                       // rounds of 1024 labels per chunk
+  __shared__ unsigned long long ball[R * 16];  // ballot of (round j, wave w)
+  __shared__ int pre[R * 16];                  // labelled positions before (j, w) inside the chunk
+  __shared__ int wtot[4];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  if (t == 0) base = 0;
-  __syncthreads();
-  for (long start = 0; start < n; start += 1024) {
-    const long i = start + t;
-    const long lab = i < n ? labels[i] : -100;
-    const int flag = lab != -100;
-    const unsigned long long bal = __ballot(flag);
-    const int prefix = __popcll(bal & ((1ULL << lane) - 1ULL));
-    if (lane == 0) wsum[w] = __popcll(bal);
+  int base = 0;
+  for (long c0 = 0; c0 < n; c0 += (long)R * 1024) {
+    long lab[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const long i = c0 + j * 1024 + t;
+      lab[j] = i < n ? labels[i] : -100;
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const unsigned long long bal = __ballot(lab[j] != -100);
+      if (lane == 0) ball[j * 16 + w] = bal;
+    }
     __syncthreads();
-    int woff = 0;
-    for (int j = 0; j < w; ++j) woff += wsum[j];
-    const int b0 = base;
-    if (flag) {
-      const int dst = b0 + woff + prefix;
+    // exclusive scan of the 256 popcounts by the first four waves (word index = j * 16 + w: the labels' own order)
+    int cnt = 0, inc = 0;
+    if (t < R * 16) {
+      cnt = __popcll(ball[t]);
+      inc = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+      }
+      if (lane == 63) wtot[w] = inc;
+    }
+    __syncthreads();
+    if (t < R * 16) {
+      int woff = 0;
+      for (int k = 0; k < w; ++k) woff += wtot[k];
+      pre[t] = woff + inc - cnt;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      if (lab[j] == -100) continue;
+      const long i = c0 + j * 1024 + t;
+      const int dst = base + pre[j * 16 + w] + __popcll(ball[j * 16 + w] & below);
       const long b = i / half;
       const long pos = b * S + offset + (i - b * half);
       rows_out[dst] = row_of_pos ? row_of_pos[pos] : (int)pos;   // packed layout: a labelled position always has a row
-      targets_out[dst] = (int)lab;
+      targets_out[dst] = (int)lab[j];
     }
-    __syncthreads();
-    if (t == 0) {
-      int tot = 0;
-      for (int j = 0; j < 16; ++j) tot += wsum[j];
-      base = b0 + tot;
-    }
-    __syncthreads();
+    base += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();   // (the next chunk overwrites ball / pre / wtot)
   }
   if (t == 0) *count_out = base;
 }

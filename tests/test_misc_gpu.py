@@ -72,6 +72,33 @@ def test_batched_transpose_refreshes_many_tensors_in_one_launch(hip):
         assert (out[:, rows:] == 0).all()
 
 
+@pytest.mark.parametrize("B,half,frac", [(1, 7, 0.5), (3, 333, 0.15), (64, 256, 0.15), (150, 256, 0.15), (64, 256, 0.0), (17, 256, 1.0)])
+def test_label_compact_any_size_with_a_row_map(hip, B, half, frac):
+    """stonk_label_compact in chunks of 16 384 labels: fewer than one round of 1024, exactly one chunk, several chunks with a
+    ragged last one, nothing labelled, everything labelled - order, targets, count; with the packed layout's row map."""
+    S = 2 * half
+    g = torch.Generator().manual_seed(B * 1000 + half)
+    labels = torch.full((B, half), -100, dtype=torch.long)
+    pick = torch.rand(B, half, generator=g) < frac
+    labels[pick] = torch.randint(0, 5000, (int(pick.sum()),), generator=g)
+    labels = labels.cuda()
+    n = B * half
+    row_of_pos = torch.randperm(B * S, generator=g).to(torch.int32).cuda()
+    for rmap in (None, row_of_pos):
+        rows = torch.full((n,), -1, device="cuda", dtype=torch.int32)
+        tg = torch.full((n,), -1, device="cuda", dtype=torch.int32)
+        cnt = torch.full((1,), -5, device="cuda", dtype=torch.int32)
+        hip.call("stonk_label_compact", hip.ptr(labels), n, half, S, half, hip.ptr(rows), hip.ptr(tg), hip.ptr(cnt),
+                 hip.ptr(rmap), hip.stream_ptr())
+        idx = (labels.view(-1) != -100).nonzero().squeeze(1)
+        c = cnt.item()
+        assert c == idx.numel()
+        pos = (idx // half) * S + half + idx % half
+        exp_rows = pos if rmap is None else rmap[pos].long()
+        assert torch.equal(rows[:c].long(), exp_rows) and torch.equal(tg[:c].long(), labels.view(-1)[idx])
+        assert (rows[c:] == -1).all() and (tg[c:] == -1).all()
+
+
 def test_label_compact_gather_scatter(hip):
     B, half, S, H = 5, 256, 512, 64
     g = torch.Generator().manual_seed(0)

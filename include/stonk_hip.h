@@ -73,6 +73,11 @@ int stonk_layernorm_bwd(const void* dy, const void* x, const float* mean, const 
                         void* dx, void* dx_drop, float* dgamma, float* dbeta, int64_t rows, int H, int flags,
                         float drop_p_in, uint32_t seed_in, float drop_p_out, uint32_t seed_out, float* partial_ws,
                         int64_t ws_floats, void* stream);
+/* With STONK_LN_DEFER_REDUCE in `flags` (workspace required) stonk_layernorm_bwd leaves the per-workgroup dgamma / dbeta
+ * partial sums in `partial_ws`; this adds them into dgamma / dbeta - same `rows` and `H` as that call - on any stream
+ * ordered after it. The training step runs it on its weight-gradient stream: only the optimizer waits for these two
+ * vectors (autograd accumulates them at the same point: hf:modeling_bert.py:107 / :292 / :350 / :479 backward). */
+int stonk_layernorm_bwd_reduce(const float* partial_ws, int64_t rows, int H, float* dgamma, float* dbeta, void* stream);
 
 /* inputs_embeds + position + token-type embeddings -> LayerNorm -> dropout, in one pass:
  *   row (b,s<half)  = text_hidden[b*half+s]          (frozen LM backbone output, bf16)

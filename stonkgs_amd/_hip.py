@@ -28,6 +28,7 @@ EPI_AUX_GRAD = 1 << 8   # aux = gelu'(pre-activation): stored by SAVE_PREACT (wi
 GEMM_AUTO, GEMM_TILE128, GEMM_WAVE8, GEMM_WAVE4, GEMM_WAVE4_192, GEMM_DISPATCHED, GEMM_DISPATCHED2 = 0, 1, 2, 3, 4, 5, 6   # stonk_gemm_nt_bf16 `kernel`
 GEMM_ASM4, GEMM_ASM4_192 = 7, 8   # the written-out four-wave kernel (gemm_a4.hip), 256x256 / 256x192 tiles
 LN_DROPOUT = 1 << 0
+LN_DEFER_REDUCE = 1 << 1   # stonk_layernorm_bwd leaves its partial sums for stonk_layernorm_bwd_reduce
 SMALL_TANH = 1
 SMALL_X_F32 = 16
 LOSS_MSE, LOSS_MSE_BROADCAST, LOSS_BCE = 0, 1, 2
@@ -43,6 +44,7 @@ _SIGNATURES = {
     "stonk_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _i32, _f32, _u32, _vp],
     "stonk_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _u32, _f32, _u32,
                             _vp, _i64, _vp],
+    "stonk_layernorm_bwd_reduce": [_vp, _i64, _i32, _vp, _vp, _vp],
     "stonk_joint_embed_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                                  _i64, _i32, _f32, _i32, _f32, _u32, _vp, _vp, _i64, _vp],
     "stonk_unpad_plan": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],

@@ -436,4 +436,6 @@ extern "C" int stonk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   }
 }
 
-extern "C" int stonk_abi_version(void) { return 4; }   // 4: stonk_comm_*, STONK_GEMM_ASM4*, written-out TN kernel behind split_k <= 0
+// 4: stonk_comm_*, STONK_GEMM_ASM4*, written-out TN kernel behind split_k <= 0; 5: stonk_layernorm_bwd_reduce + STONK_LN_DEFER_REDUCE,
+// the ASM4 kernels' fp16 / split-K atomic forms, 256 gradient-norm slots (stonk_sumsq_workspace_floats)
+extern "C" int stonk_abi_version(void) { return 5; }

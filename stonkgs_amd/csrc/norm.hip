@@ -753,6 +753,7 @@ extern "C" int stonk_layernorm_bwd(const void* dy, const void* x, const float* m
   const int grid = ln_grid(rows) < 1024 ? ln_grid(rows) : 1024;
   // workspace (grid x 2H floats) given: partial sums + a reduce kernel instead of contended atomics
   float* ws = (dgamma && partial_ws && ws_floats >= (int64_t)grid * 2 * H) ? partial_ws : nullptr;
+  if (flags & STONK_LN_DEFER_REDUCE) STONK_CHECK_ARG(ws != nullptr, STONK_EINVAL);   // (needs the workspace)
   const bool din = (flags & STONK_LN_DROPOUT) != 0, dout = dx_drop != nullptr;
 #define LN_BWD_LANE(EPL, DI, DO)                                                                                       \
   hipLaunchKernelGGL((layernorm_bwd_lane_kernel<EPL, DI, DO>), dim3(grid), dim3(256), lds, (hipStream_t)stream,         \
@@ -776,9 +777,22 @@ extern "C" int stonk_layernorm_bwd(const void* dy, const void* x, const float* m
                                     dgamma, dbeta, (long)rows, H, flags, stonk_drop_thr32(drop_p_in),
                                     1.f / (1.f - drop_p_in), stonk_seed_mix(seed_in), stonk_drop_thr32(drop_p_out),
                                     1.f / (1.f - drop_p_out), stonk_seed_mix(seed_out), ws));
-  if (ws)
+  // STONK_LN_DEFER_REDUCE: the partial sums stay in the workspace; the caller finishes with stonk_layernorm_bwd_reduce
+  // (the training step puts that launch on its weight-gradient stream: nothing on the main chain waits for dgamma / dbeta)
+  if (ws && !(flags & STONK_LN_DEFER_REDUCE))
     hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((2 * H + 255) / 256, 32), dim3(256), 0, (hipStream_t)stream, ws, grid,
                        H, dgamma, dbeta);
+  return stonk_launch_status();
+}
+
+extern "C" int stonk_layernorm_bwd_reduce(const float* partial_ws, int64_t rows, int H, float* dgamma, float* dbeta,
+                                          void* stream) {
+  STONK_CHECK_ARG(partial_ws && dgamma && dbeta, STONK_EINVAL);
+  STONK_CHECK_ARG(rows >= 0 && H > 0 && H % 8 == 0 && H <= 4096, STONK_ESHAPE);
+  if (rows == 0) return STONK_OK;
+  const int grid = ln_grid(rows) < 1024 ? ln_grid(rows) : 1024;   // (as stonk_layernorm_bwd launched for these rows)
+  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((2 * H + 255) / 256, 32), dim3(256), 0, (hipStream_t)stream, partial_ws,
+                     grid, H, dgamma, dbeta);
   return stonk_launch_status();
 }
 

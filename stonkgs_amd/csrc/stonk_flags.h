@@ -39,6 +39,8 @@
                                  there split_k is an UPPER bound: the kernel takes as many shares as fill its grid once */
 // --- stonk_layernorm_* `flags` ---
 #define STONK_LN_DROPOUT (1 << 0)
+#define STONK_LN_DEFER_REDUCE (1 << 1) /* stonk_layernorm_bwd: leave the dgamma / dbeta partial sums in the workspace; \
+                                        stonk_layernorm_bwd_reduce adds them (on any stream, after this launch) */
 // --- stonk_small_linear_* `act` ---
 #define STONK_SMALL_TANH 1
 #define STONK_SMALL_X_F32 16 /* x is fp32 (default bf16) */

@@ -93,6 +93,11 @@ class Engine:
         # prefetch; measured on one GPU with nothing beside it (tools/ab_step.py dispatched_pairs engine.comm_overlap=1)
         self.dispatched_pairs = True
         self.decoder_dgrad_256 = True
+        # LayerNorm backward: dgamma / dbeta partial sums added on the weight-gradient stream (stonk_layernorm_bwd_reduce) instead
+        # of behind the kernel on the main one. Measured: +0.16 ms (26.87 against 26.71, tools/ab_step.py ln_reduce_side) - the
+        # 26 launches of ~7 us it takes off the main chain cost less there than the event record / wait pairs that order them: off
+        self.ln_reduce_side = False
+        self._ln_done = {}
         # weight gradients whose row count is a multiple of 128 only (the text decoder's 29 056 = 113.5 x 256) on the
         # written-out 256x256 kernel as well (its last row tile is half empty, the buffers' range checks drop what it
         # adds): correct, and no change to the step - 26.76 against 26.77 ms interleaved (tools/ab_step.py tn_ragged) - so off
@@ -242,6 +247,37 @@ class Engine:
         count it can be asked for (every token of the largest batch seen so far)."""
         n = int(hip.lib().stonk_layernorm_bwd_workspace_floats(1 << 30, self.cfg.hidden_size))
         return self.buf("ln.ws", (n,), F32)
+
+    def ln_bwd(self, dy, x, mean, rstd, gamma, dx, dx_drop, dgamma, dbeta, rows, H, flags, p_in, seed_in, p_out, seed_out):
+        """stonk_layernorm_bwd on the current stream. With the weight gradients on their own stream (`overlap_wgrad`) the sum
+        of the per-workgroup dgamma / dbeta partials can go there too (`ln_reduce_side`; off - measured slower, see __init__):
+        nothing on the main chain reads the two vectors. The partials then need a workspace of their own until that launch
+        has run: a ring of four, each slot guarded by the event of the reduce that last read it."""
+        st = hip.stream_ptr()
+        args = (hip.ptr(dy), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(dx), hip.ptr(dx_drop),
+                hip.ptr(dgamma), hip.ptr(dbeta), rows, H)
+        if not (self.ln_reduce_side and self.overlap_wgrad) or dgamma is None or rows == 0:
+            ws = self.ln_ws()
+            hip.call("stonk_layernorm_bwd", *args, flags, p_in, seed_in, p_out, seed_out, ws.data_ptr(), ws.numel(), st)
+            return
+        n = int(hip.lib().stonk_layernorm_bwd_workspace_floats(1 << 30, self.cfg.hidden_size))
+        slot = self._ln_slot = (getattr(self, "_ln_slot", -1) + 1) % 4
+        ws = self.buf(f"ln.ws.ring{slot}", (n,), F32)
+        last = self._ln_done.get(slot)
+        if last is not None:
+            torch.cuda.current_stream().wait_event(last)   # (the reduce of four LayerNorms ago: done long since)
+        hip.call("stonk_layernorm_bwd", *args, flags | hip.LN_DEFER_REDUCE, p_in, seed_in, p_out, seed_out, ws.data_ptr(),
+                 ws.numel(), st)
+        if self._wstream is None:
+            self._wstream = torch.cuda.Stream(device=self.device)
+        ready = torch.cuda.Event()
+        ready.record()
+        self._wstream.wait_event(ready)
+        with torch.cuda.stream(self._wstream):
+            hip.call("stonk_layernorm_bwd_reduce", ws.data_ptr(), rows, H, hip.ptr(dgamma), hip.ptr(dbeta), hip.stream_ptr())
+            done = torch.cuda.Event()
+            done.record()
+        self._ln_done[slot] = done
 
     def check_errors(self) -> None:
         """Raise for any flag the kernels set (one tiny D2H copy; call where a sync is acceptable)."""
@@ -486,10 +522,9 @@ class Engine:
         ds2 = self.buf(f"b.ds2.{par}", (cap, H))
         df = self.buf(f"b.df.{par}", (cap, H)) if p_hid > 0 else None
         Tf = T if rd is None else rd["T"]          # rows the feed-forward block ran on
-        hip.call("stonk_layernorm_bwd", dy.data_ptr(), sv["s2"].data_ptr(), sv["st2"][0].data_ptr(),
-                 sv["st2"][1].data_ptr(), f(prefix + ".output.LayerNorm.weight").data_ptr(), ds2.data_ptr(), hip.ptr(df),
-                 g_(prefix + ".output.LayerNorm.weight").data_ptr(), g_(prefix + ".output.LayerNorm.bias").data_ptr(),
-                 Tf, H, 0, 0.0, 0, p_hid, self.seed(lidx, 3), self.ln_ws().data_ptr(), self.ln_ws().numel(), st)
+        self.ln_bwd(dy, sv["s2"], sv["st2"][0], sv["st2"][1], f(prefix + ".output.LayerNorm.weight"), ds2, df,
+                    g_(prefix + ".output.LayerNorm.weight"), g_(prefix + ".output.LayerNorm.bias"), Tf, H, 0, 0.0, 0, p_hid,
+                    self.seed(lidx, 3))
         if df is None:
             df = ds2
         # ---- FFN down: wgrad, bias grad, dgrad fused with GELU'
@@ -516,11 +551,9 @@ class Engine:
         # ---- LN1 backward
         ds1 = self.buf(f"b.ds1.{par}", (cap, H))
         da = self.buf(f"b.da.{par}", (cap, H)) if p_hid > 0 else None
-        hip.call("stonk_layernorm_bwd", dh1.data_ptr(), sv["s1"].data_ptr(), sv["st1"][0].data_ptr(),
-                 sv["st1"][1].data_ptr(), f(prefix + ".attention.output.LayerNorm.weight").data_ptr(), ds1.data_ptr(),
-                 hip.ptr(da), g_(prefix + ".attention.output.LayerNorm.weight").data_ptr(),
-                 g_(prefix + ".attention.output.LayerNorm.bias").data_ptr(), Ta, H, 0, 0.0, 0, p_hid, self.seed(lidx, 2),
-                 self.ln_ws().data_ptr(), self.ln_ws().numel(), st)
+        self.ln_bwd(dh1, sv["s1"], sv["st1"][0], sv["st1"][1], f(prefix + ".attention.output.LayerNorm.weight"), ds1, da,
+                    g_(prefix + ".attention.output.LayerNorm.weight"), g_(prefix + ".attention.output.LayerNorm.bias"), Ta, H, 0,
+                    0.0, 0, p_hid, self.seed(lidx, 2))
         if da is None:
             da = ds1
         # ---- attention output projection
@@ -924,10 +957,9 @@ class Engine:
             notify(wname)
         # ---- head transform backward
         dgt = self.buf("b.dgt", (cap_rows, H))
-        hip.call("stonk_layernorm_bwd", dt.data_ptr(), sv["gt"].data_ptr(), sv["stt"][0].data_ptr(),
-                 sv["stt"][1].data_ptr(), f("cls.predictions.transform.LayerNorm.weight").data_ptr(), dgt.data_ptr(), 0,
-                 g_("cls.predictions.transform.LayerNorm.weight").data_ptr(),
-                 g_("cls.predictions.transform.LayerNorm.bias").data_ptr(), T, H, 0, 0.0, 0, 0.0, 0, self.ln_ws().data_ptr(), self.ln_ws().numel(), st)
+        self.ln_bwd(dt, sv["gt"], sv["stt"][0], sv["stt"][1], f("cls.predictions.transform.LayerNorm.weight"), dgt, None,
+                    g_("cls.predictions.transform.LayerNorm.weight"), g_("cls.predictions.transform.LayerNorm.bias"), T, H, 0,
+                    0.0, 0, 0.0, 0)
         dut = self.buf("b.dut", (cap_rows, H))
         hip.call("stonk_gelu_bwd_bf16", dgt.data_ptr(), sv["ut"].data_ptr(), dut.data_ptr(), T * H, st)
         self.wgrad(dut, sv["seq_out"], g_("cls.predictions.transform.dense.weight"),
@@ -1013,10 +1045,9 @@ class Engine:
         # ---- embeddings LayerNorm, position / token-type embeddings
         dsum = self.buf("b.dsum0", (cap, H))
         p_hid = sv["p_hid"]
-        hip.call("stonk_layernorm_bwd", dy.data_ptr(), sv["sum0"].data_ptr(), sv["st0"][0].data_ptr(),
-                 sv["st0"][1].data_ptr(), f("bert.embeddings.LayerNorm.weight").data_ptr(), dsum.data_ptr(), 0,
-                 g_("bert.embeddings.LayerNorm.weight").data_ptr(), g_("bert.embeddings.LayerNorm.bias").data_ptr(), T, H,
-                 hip.LN_DROPOUT if p_hid > 0 else 0, p_hid, self.seed(200, 0), 0.0, 0, self.ln_ws().data_ptr(), self.ln_ws().numel(), st)
+        self.ln_bwd(dy, sv["sum0"], sv["st0"][0], sv["st0"][1], f("bert.embeddings.LayerNorm.weight"), dsum, None,
+                    g_("bert.embeddings.LayerNorm.weight"), g_("bert.embeddings.LayerNorm.bias"), T, H,
+                    hip.LN_DROPOUT if p_hid > 0 else 0, p_hid, self.seed(200, 0), 0.0, 0)
         hip.call("stonk_embed_grad", dsum.data_ptr(), hip.ptr(sv["token_type_ids"]),
                  g_("bert.embeddings.position_embeddings.weight").data_ptr(),
                  g_("bert.embeddings.token_type_embeddings.weight").data_ptr(), B, S, H, cfg.type_vocab_size,

@@ -105,7 +105,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _hip.lib().stonk_abi_version() == 4
+    assert _hip.lib().stonk_abi_version() == 5
     assert _hip.lib().stonk_sumsq_workspace_floats() == 257   # (256 partial-sum slots + the ticket word)
     assert _hip.lib().stonk_layernorm_bwd_workspace_floats(32768, 768) == 1024 * 2 * 768   # (no GPU touched: a size query)
     assert _hip.lib().stonk_layernorm_bwd_workspace_floats(0, 768) == 0

@@ -57,6 +57,29 @@ def test_layernorm_fwd_bwd(hip, rows, H):
     torch.testing.assert_close(dx.float(), xf.grad, rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(dgamma, gf.grad, rtol=1e-3, atol=1e-2)
     torch.testing.assert_close(dbeta, bf.grad, rtol=1e-3, atol=1e-2)
+    # STONK_LN_DEFER_REDUCE: the partial sums stay in the workspace until stonk_layernorm_bwd_reduce adds them - on another
+    # stream, ordered by an event, as the training step does; same dx, the same sums (the partials are added in the same order)
+    dx2 = torch.empty_like(x)
+    dg2 = torch.full((H,), 3.0, device="cuda")
+    db2 = torch.full((H,), -2.0, device="cuda")
+    ws2 = torch.empty(int(hip.lib().stonk_layernorm_bwd_workspace_floats(rows, H)), device="cuda")
+    hip.call("stonk_layernorm_bwd", hip.ptr(dy), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(dx2),
+             0, hip.ptr(dg2), hip.ptr(db2), rows, H, hip.LN_DEFER_REDUCE, 0.0, 0, 0.0, 0, hip.ptr(ws2), ws2.numel(),
+             hip.stream_ptr())
+    torch.cuda.synchronize()
+    assert (dg2 == 3.0).all() and (db2 == -2.0).all() and torch.equal(dx2, dx)     # nothing added yet
+    side = torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    ev.record()
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        hip.call("stonk_layernorm_bwd_reduce", hip.ptr(ws2), rows, H, hip.ptr(dg2), hip.ptr(db2), hip.stream_ptr())
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dg2 - 3.0, dgamma, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(db2 + 2.0, dbeta, rtol=1e-5, atol=1e-4)
+    with pytest.raises(hip.StonkHipError, match="-1"):   # deferring needs the workspace
+        hip.call("stonk_layernorm_bwd", hip.ptr(dy), hip.ptr(x), hip.ptr(mean), hip.ptr(rstd), hip.ptr(gamma), hip.ptr(dx2),
+                 0, hip.ptr(dg2), hip.ptr(db2), rows, H, hip.LN_DEFER_REDUCE, 0.0, 0, 0.0, 0, 0, 0, hip.stream_ptr())
 
 
 @pytest.mark.parametrize("rows,H", [(512, 768), (300, 1024), (129, 512), (200, 640)])
